@@ -1,0 +1,225 @@
+/*
+ * pathtracer_amd — C ABI of the MI355X (gfx950) bounce-loop path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes and returns an
+ * int status (PT_OK == 0).  The reference renderer (LewisBray/PathTracer) has no
+ * plugin / FFI interface: all its functions are `static` in one translation unit
+ * (src/main.cpp:11-18).  The seam this library replaces is the row work-queue
+ * payload `RenderWorkQueue::Entry` (src/main.cpp:42-54) that is handed to
+ * `render_scanline` (src/main.cpp:74-123), plus the host entry points that feed it.
+ * Each declaration below cites the reference code it stands in for.
+ *
+ * All floating point is IEEE binary64 ("real" is double, src/types.h:9); all
+ * records are binary compatible with the reference's structs so that a reference
+ * build can pass its own arrays straight through.
+ */
+#ifndef PATHTRACER_AMD_H
+#define PATHTRACER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (the reference only asserts; src/model_loading.cpp:21-36) ---- */
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARGUMENT = 1,
+    PT_ERR_IO = 2,
+    PT_ERR_DEVICE = 3,
+    PT_ERR_OUT_OF_MEMORY = 4,
+    PT_ERR_UNSUPPORTED = 5
+};
+
+/* ---- plain records, layout-identical to the reference's ---- */
+typedef struct PtVec3 { double x, y, z; } PtVec3;                       /* src/linear_algebra.h:6-10  (24 B) */
+typedef struct PtMat3 { double rows[3][3]; } PtMat3;                    /* src/linear_algebra.h:22-24 (72 B) */
+typedef struct PtColour { double r, g, b; } PtColour;                   /* src/colour.h:6-10          (24 B) */
+typedef struct PtRay { PtVec3 origin, direction; } PtRay;               /* src/geometry.h:9-12        (48 B) */
+typedef struct PtAabb { PtVec3 min, max; } PtAabb;                      /* src/geometry.h:14-17       (48 B) */
+typedef struct PtSphere { PtVec3 centre; double radius; } PtSphere;     /* src/geometry.h:28-31       (32 B) */
+typedef struct PtTriangle { PtVec3 a, b, c; } PtTriangle;               /* src/geometry.h:42-46       (72 B) */
+
+/* src/bvh.h:8-13.  A leaf has left == 0 && right == 0 and names its primitive in
+ * `index`; the root is node 0; a tree over N primitives has 2N-1 nodes in pre-order. (64 B) */
+typedef struct PtBvhNode {
+    PtAabb aabb;
+    int32_t index, left, right;
+    int32_t pad_;
+} PtBvhNode;
+
+/* src/material.h:25-41: a 32-byte union followed by the type tag (40 B).
+ *   LAMBERTIAN    v[0..2] = albedo
+ *   METAL         v[0..2] = albedo, v[3] = fuzziness
+ *   DIELECTRIC    v[0]    = refraction index
+ *   DIFFUSE_LIGHT v[0..2] = emission colour, v[3] = emission power */
+enum { PT_LAMBERTIAN = 0, PT_METAL = 1, PT_DIELECTRIC = 2, PT_DIFFUSE_LIGHT = 3 };
+typedef struct PtMaterial {
+    double v[4];
+    int32_t type;
+    int32_t pad_;
+} PtMaterial;
+
+/* src/path_tracing.h:27-35 (128 B) */
+typedef struct PtCamera {
+    PtMat3 orientation;
+    PtVec3 target;
+    double distance;
+    double fov_y;
+    double aperture;
+    double focus_distance;
+} PtCamera;
+
+/* src/path_tracing.h:9-22 `Scene`, plus the element counts the reference never
+ * stores.  All pointers are host arrays owned by the caller; a null BVH means
+ * "no primitives of that kind" exactly as in src/path_tracing.cpp:177-178. */
+typedef struct PtSceneDesc {
+    const PtMaterial* materials;
+    int32_t material_count;
+
+    const PtSphere* spheres;
+    int32_t sphere_count;
+    const PtBvhNode* sphere_bvh;
+    int32_t sphere_bvh_node_count;
+    const int32_t* sphere_material_indices;
+
+    const PtTriangle* triangles;
+    int32_t triangle_count;
+    const PtBvhNode* triangle_bvh;
+    int32_t triangle_bvh_node_count;
+    const int32_t* triangle_material_indices;
+
+    PtColour background_gradient_start;
+    PtColour background_gradient_end;
+} PtSceneDesc;
+
+/* `RenderWorkQueue::Entry` (src/main.cpp:42-54) generalised from one row and one
+ * sample to a row range and a sample range, with the compile-time constants
+ * CLIENT_WIDTH / CLIENT_HEIGHT (src/main.cpp:38-39) and MAX_BOUNCE_COUNT
+ * (src/path_tracing.cpp:172) made run-time fields.  Row 0 is the bottom row. */
+typedef struct PtFrame {
+    int32_t width, height;
+    int32_t row_begin, row_end;        /* rows [row_begin, row_end) are rendered      */
+    int32_t sample_begin, sample_count;/* samples [sample_begin, sample_begin+count)  */
+    int32_t max_bounces;               /* reference value: 50                          */
+    int32_t reserved_;
+    double aperture;
+    PtVec3 camera_position, camera_x, camera_y;
+    PtVec3 bottom_left, step_x, step_y;
+} PtFrame;
+
+typedef struct PtScene PtScene;          /* device-resident scene (opaque)  */
+typedef struct PtHostScene PtHostScene;  /* host-side scene arrays (opaque) */
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* pt_last_error(void);
+
+/* ---------------- host entry points kept from the reference ---------------- */
+
+/* load_triangles_file (src/model_loading.cpp:10-39): whole file = raw 72-byte
+ * records.  *triangles is malloc'ed; release with pt_free. */
+int pt_load_triangles_file(const char* filename, PtTriangle** triangles, int64_t* count);
+/* save_triangles_file (src/model_loading.cpp:41-61). */
+int pt_save_triangles_file(const char* filename, const PtTriangle* triangles, int64_t count);
+void pt_free(void* p);
+
+/* construct_triangle_bvh / construct_sphere_bvh (src/bvh.cpp:81-100 / :60-79).
+ * `nodes` must hold 2*count-1 records; the output is identical, node for node,
+ * to the reference's std::vector<Node>. */
+int pt_construct_triangle_bvh(const PtTriangle* triangles, int32_t count, PtBvhNode* nodes);
+int pt_construct_sphere_bvh(const PtSphere* spheres, int32_t count, PtBvhNode* nodes);
+
+/* rotation_matrix / look_at_matrix (src/linear_algebra.cpp:81-101 / :103-122). */
+int pt_rotation_matrix(double angle, double axis_x, double axis_y, double axis_z, PtMat3* out);
+int pt_look_at_matrix(const PtVec3* position, const PtVec3* target, PtMat3* out);
+/* Camera set-up as the reference does it for each built-in scene (e.g.
+ * src/main.cpp:833-840): orientation = look_at, distance = |position - target|;
+ * focus_distance <= 0 selects "focus at the target" (focus = distance). */
+int pt_camera_look_at(const PtVec3* position, const PtVec3* target, double fov_y,
+                      double aperture, double focus_distance, PtCamera* out);
+/* Per-frame camera basis (src/main.cpp:928-930, 987-994 and get_position,
+ * src/path_tracing.cpp:229-231).  Fills every camera field of *frame plus
+ * width/height; row range = whole image, sample range = {0,1}, max_bounces = 50. */
+int pt_camera_frame(const PtCamera* camera, double aspect_ratio, int32_t width, int32_t height,
+                    PtFrame* frame);
+
+/* Built-in scenes.  PT_SCENE_MODEL is the reference's active scene
+ * (src/main.cpp:800-840) with the model file chosen by the caller; the chess
+ * scenes are this library's own definitions over the reference's six model
+ * files (the reference defines no multi-piece scene). */
+enum {
+    PT_SCENE_MODEL = 0,        /* one model file, reference materials/light/camera            */
+    PT_SCENE_CHESS6_ROW = 1,   /* pawn..king in a row, 83,504 triangles                       */
+    PT_SCENE_CHESS32 = 2,      /* 32-piece starting position + board, 422,598 triangles       */
+    PT_SCENE_CHESS32_MIXED = 3,/* same geometry, all four material types, sky-like background */
+    PT_SCENE_CHESS_GRID = 4,   /* chess32 replicated on a grid_n x grid_n lattice of boards    */
+    PT_SCENE_RANDOM_SPHERES = 5,/* src/main.cpp:516-625                                       */
+    PT_SCENE_CORNELL_BOX = 6   /* src/main.cpp:627-798                                        */
+};
+/* `path` is a .triangles file for PT_SCENE_MODEL, a directory holding
+ * pawn/rook/knight/bishop/queen/king.triangles for the chess scenes, ignored
+ * otherwise.  `param` is grid_n for PT_SCENE_CHESS_GRID, ignored otherwise. */
+int pt_host_scene_build(int32_t kind, const char* path, int32_t param, PtHostScene** out);
+int pt_host_scene_desc(const PtHostScene* scene, PtSceneDesc* desc);
+int pt_host_scene_camera(const PtHostScene* scene, PtCamera* camera, double* aspect_ratio);
+void pt_host_scene_destroy(PtHostScene* scene);
+
+/* Tone-map (src/main.cpp:1024-1034): out[4i+{0,1,2}] = (u8)(255 * min(sqrt(accum/sample_count), 1)),
+ * out[4i+3] = 255; BGRA order like the accumulation buffer. */
+int pt_tonemap_bgra8(const double* accum, int64_t pixel_count, int32_t sample_count, uint8_t* out);
+/* write_pixel_data_to_file (src/main.cpp:179-212): raw RGBA8 (B and R swapped on
+ * the way out), rows bottom-to-top, no header.  `bgra` is left unchanged. */
+int pt_write_pixel_data_file(const char* filename, const uint8_t* bgra, int64_t pixel_count);
+
+/* ---------------- the GPU path ---------------- */
+
+/* Copies the scene (src/path_tracing.h:9-22) into the HBM of `device` and lays
+ * the BVH out for traversal.  Validates every index the reference would follow
+ * blindly.  The caller keeps ownership of the arrays in *desc. */
+int pt_scene_create(const PtSceneDesc* desc, int32_t device, PtScene** out);
+void pt_scene_destroy(PtScene* scene);
+
+/* render_scanline (src/main.cpp:74-123) over frame->rows x frame->samples:
+ * for every pixel, in ascending sample order,
+ *   accum[4*(row*width+col) + {0,1,2,3}] += {b, g, r, 1.0}.
+ * `accum` is a caller-owned host buffer of 4*width*height doubles. */
+int pt_render(PtScene* scene, const PtFrame* frame, double* accum);
+/* Same, with `accum_device` in the HBM of the scene's device and the work
+ * enqueued on `hip_stream` (a hipStream_t; null = the default stream).  Returns
+ * after the launch; the caller synchronises the stream. */
+int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
+
+/* First-bounce `ClosestShapeIntersection.index` of both traversals
+ * (src/path_tracing.cpp:177-178) for sample frame->sample_begin, -1 = miss.
+ * Host buffers of width*height int32 each; rows outside the frame's row range
+ * are left untouched.  Either pointer may be null. */
+int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_index, int32_t* sphere_index);
+
+/* Kernel time in milliseconds of the most recent pt_render / pt_render_device on
+ * this scene, measured with HIP events on the launch stream (blocks until the
+ * launch has finished).  Not in the reference: measurement only. */
+int pt_last_render_ms(PtScene* scene, float* ms);
+
+/* Device self-test hook: evaluates one device-side building block of the path
+ * on `n` packed input records and copies the results back (host pointers).
+ * Not in the reference; it exists so the device arithmetic can be checked
+ * against known answers one function at a time. */
+enum {
+    PT_EVAL_NOISE_1D = 0,          /* in: int32                    out: uint32            (src/rng.cpp:5-20)    */
+    PT_EVAL_NOISE_3D = 1,          /* in: int32[3]                 out: uint32            (src/rng.cpp:22-28)   */
+    PT_EVAL_XORSHIFT_REAL = 2,     /* in: uint32                   out: uint32,pad,double (src/rng.cpp:63-69, :30-32) */
+    PT_EVAL_RANDOM_UNIT_VECTOR = 3,/* in: double[3]                out: double[3]         (src/rng.cpp:34-61)   */
+    PT_EVAL_RAY_AABB = 4,          /* in: ray[6], aabb[6]          out: double[2]         (src/geometry.cpp:7-37)   */
+    PT_EVAL_RAY_SPHERE = 5,        /* in: ray[6], sphere[4]        out: double[3] (valid,min,max) (src/geometry.cpp:59-82) */
+    PT_EVAL_RAY_TRIANGLE = 6,      /* in: ray[6], tri[9]           out: double[2] (valid,t)       (src/geometry.cpp:106-133) */
+    PT_EVAL_UNIT_NORMAL = 7,       /* in: tri[9]                   out: double[3]         (src/geometry.cpp:84-90)  */
+    PT_EVAL_SCATTER = 8,           /* in: ray[6], material(5 dbl: v[4], type), point[3], normal[3]  out: double[7] (valid, ray[6]) (src/path_tracing.cpp:35-97) */
+    PT_EVAL_SQRT_DIV = 9           /* in: double[2] (a,b)          out: double[2] (sqrt(a), a/b) */
+};
+int pt_device_eval(int32_t device, int32_t op, const void* in, int64_t n, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHTRACER_AMD_H */
