@@ -1,0 +1,38 @@
+# Builds libpathtracer_amd.so (host C++ + gfx950 HIP kernels behind the C ABI of
+# include/pathtracer_amd.h) in-tree, and the CPU checkers under oracle/.
+#
+# -ffp-contract=off everywhere: the path's results are defined by unfused IEEE binary64
+# operations, on the host (precomputed triangle records, camera, BVH boxes) and on the device.
+
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+ARCH     ?= gfx950
+CSRC     := pathtracer_amd/csrc
+LIB      := pathtracer_amd/libpathtracer_amd.so
+
+HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wextra -Wno-unused-parameter
+HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter $(EXTRA_HIPFLAGS)
+
+HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp
+HOST_OBJS := $(HOST_SRCS:.cpp=.o)
+HIP_OBJS  := $(CSRC)/pt_gpu.o
+
+all: $(LIB) oracle
+
+$(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/pt_internal.h include/pathtracer_amd.h
+	$(CXX) $(HOSTFLAGS) -c -o $@ $<
+
+$(CSRC)/pt_gpu.o: $(CSRC)/pt_gpu.hip $(CSRC)/pt_device.hpp $(CSRC)/pt_internal.h include/pathtracer_amd.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(HOST_OBJS) $(HIP_OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(HOST_OBJS) $(HIP_OBJS) -pthread
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f $(HOST_OBJS) $(HIP_OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -107,7 +107,14 @@ typedef struct PtFrame {
     double aperture;
     PtVec3 camera_position, camera_x, camera_y;
     PtVec3 bottom_left, step_x, step_y;
+    /* Sharding of the row range over several callers (one per GPU), the way the reference's
+     * work queue deals rows to threads: rows are taken in blocks of PT_ROW_BLOCK starting at
+     * row_begin, and block b is rendered only if b % shard_count == shard_index.
+     * shard_count <= 1 renders every row. */
+    int32_t shard_index, shard_count;
 } PtFrame;
+
+enum { PT_ROW_BLOCK = 8 };
 
 typedef struct PtScene PtScene;          /* device-resident scene (opaque)  */
 typedef struct PtHostScene PtHostScene;  /* host-side scene arrays (opaque) */

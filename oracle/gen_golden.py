@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — writes tests/golden/*.npz from the reference's own code.
+
+Every expected value in the fixtures is produced by oracle/_ref/libptref.so, i.e. by the
+reference's sources compiled in place (see ref_harness.cpp).  Inputs are seeded here; the
+scene inputs are the reference's model files (assets/models, byte-identical copies of
+/root/reference/models).  Run from the repo root in a container that has /root/reference:
+
+    make -C oracle ref && python oracle/gen_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.bindings import RefLib  # noqa: E402
+from pathtracer_amd.ctypes_abi import MATERIAL_DTYPE  # noqa: E402
+
+MODELS = os.path.join(ROOT, "assets", "models")
+OUT = os.path.join(ROOT, "tests", "golden")
+PIECES = ["pawn", "rook", "knight", "bishop", "queen", "king"]
+PI_F = float(np.float32(3.14159265358979323846264))
+
+
+def unit_rows(rng, n):
+    v = rng.normal(size=(n, 3))
+    v /= np.sqrt((v * v).sum(1))[:, None]
+    # re-normalise the way the reference does so |d|^2 - 1 is far inside its 1e-6 assert
+    return v
+
+
+def id_hash(indices):
+    """Sum over hit pixels of (u32)(index * 2654435761): order-free digest of a hit map."""
+    idx = indices[indices >= 0].astype(np.uint64)
+    return int(((idx * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)).sum())
+
+
+def chess6_row_arrays(ref):
+    """The six-piece row: piece i at x = -100 + 40 i, model-scene materials and light."""
+    rot = ref.rotation_matrix(-PI_F / 2.0, 1.0, 0.0, 0.0)
+    tris = []
+    for i, name in enumerate(PIECES):
+        t = np.fromfile(os.path.join(MODELS, name + ".triangles")).reshape(-1, 3, 3)
+        # row-vector form of M*v with the reference's left-to-right sum of three products
+        x = t[..., 0:1] * rot[:, 0] + t[..., 1:2] * rot[:, 1] + t[..., 2:3] * rot[:, 2]
+        x = x + np.array([np.float32(-100.0) + np.float32(40.0) * np.float32(i), 0.0, 0.0])
+        tris.append(x.reshape(-1, 9))
+    tris = np.concatenate(tris)
+    mats = np.zeros(2, MATERIAL_DTYPE)
+    mats[0]["v"][:3] = [np.float32(6.0) / np.float32(255.0), np.float32(4.0) / np.float32(255.0), np.float32(3.0) / np.float32(255.0)]
+    mats[0]["type"] = 0
+    mats[1]["v"] = [1.0, 1.0, 1.0, 10.0]
+    mats[1]["type"] = 3
+    g = float(np.float32(0.01))
+    return {
+        "materials": mats,
+        "spheres": np.array([[20.0, 80.0, 10.0, 20.0]]),
+        "sphere_material_indices": np.array([1], np.int32),
+        "triangles": tris,
+        "triangle_material_indices": np.zeros(len(tris), np.int32),
+        "background": np.array([[g, g, g], [g, g, g]]),
+    }
+
+
+def main():
+    ref = RefLib()
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20240611)
+    g = {}
+
+    # ---- (1) hashes and the xorshift stream
+    ints = np.concatenate([np.array([0, 1, -1, -2**31, 2**31 - 1, 479001599], np.int64), rng.integers(-2**31, 2**31, 250)])
+    g["noise1d_in"] = ints.astype(np.int32)
+    g["noise1d_out"] = np.array([ref.noise_1d(int(x)) for x in ints], np.uint32)
+    grid = np.array([(r, c, s) for r in (0, 1, 7, 359, 1079, 2159) for c in (0, 1, 10, 11, 12, 639, 1919, 3839) for s in (0, 1, 15, 255, 1023)], np.int32)
+    g["noise3d_in"] = grid
+    g["noise3d_out"] = np.array([ref.noise_3d(*map(int, row)) for row in grid], np.uint32)
+    seeds = np.concatenate([np.array([0, 1, 479001599, 0xFFFFFFFF], np.uint64), rng.integers(0, 2**32, 252, dtype=np.uint64)]).astype(np.uint32)
+    g["xorshift_in"] = seeds
+    nxt = np.array([ref.random_number(int(s)) for s in seeds], np.uint32)
+    g["xorshift_out"] = nxt
+    g["xorshift_real"] = np.array([ref.real_from_rng(int(s)) for s in nxt])
+
+    # ---- (2) random_unit_vector
+    dirs = unit_rows(rng, 1024)
+    dirs[:6] = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]], float)
+    g["ruv_in"] = dirs
+    g["ruv_out"] = ref.random_unit_vector(dirs)
+
+    # ---- (3) ray / box, sphere, triangle
+    n = 4096
+    o = rng.uniform(-50, 50, (n, 3))
+    d = unit_rows(rng, n)
+    d[:64] = np.eye(3)[rng.integers(0, 3, 64)] * rng.choice([-1.0, 1.0], (64, 1))   # axis-parallel: infinite reciprocals
+    rays = np.concatenate([o, d], 1)
+    lo = rng.uniform(-60, 40, (n, 3))
+    boxes = np.concatenate([lo, lo + rng.uniform(0.0, 40.0, (n, 3))], 1)
+    for k in range(64):                                                               # origin on a box plane: 0 * inf
+        boxes[k, k % 3] = rays[k, k % 3]
+    g["aabb_rays"], g["aabb_boxes"] = rays, boxes
+    g["aabb_out"] = ref.ray_aabb(rays, boxes)
+    spheres = np.concatenate([rng.uniform(-60, 60, (n, 3)), rng.uniform(-30, 30, (n, 1))], 1)
+    spheres[:256, :3] = rays[:256, :3] + rays[:256, 3:] * rng.uniform(5, 60, (256, 1))   # guaranteed hits
+    g["sphere_in"] = spheres
+    g["sphere_out"] = ref.ray_sphere(rays, spheres)
+    a = rng.uniform(-60, 60, (n, 3))
+    tris = np.concatenate([a, a + rng.normal(0, 15, (n, 3)), a + rng.normal(0, 15, (n, 3))], 1)
+    # aim three quarters of the rays at their triangle (interior, edges and vertices) so hits are common
+    w = rng.dirichlet([1, 1, 1], n)
+    w[:128] = np.array([0.5, 0.5, 0.0])
+    w[128:256] = np.array([1.0, 0.0, 0.0])
+    target = (tris.reshape(n, 3, 3) * w[:, :, None]).sum(1)
+    aimed = target - o
+    aimed /= np.sqrt((aimed * aimed).sum(1))[:, None]
+    tri_rays = rays.copy()
+    tri_rays[: 3 * n // 4, 3:] = aimed[: 3 * n // 4]
+    tris[-16:, 6:9] = tris[-16:, 3:6]                                                 # degenerate: zero-area
+    g["tri_rays"], g["tri_in"] = tri_rays, tris
+    g["tri_out"] = ref.ray_triangle(tri_rays, tris)
+    g["unit_normal_out"] = ref.unit_normal(tris[:-16])
+
+    # ---- (4) scatter, all four material types
+    m = 2048
+    normals = unit_rows(rng, m)
+    incoming = unit_rows(rng, m)
+    flip = (incoming * normals).sum(1) > 0
+    incoming[flip[: m // 2].nonzero()[0]] *= -1.0                                     # first half: front-facing
+    mats = np.zeros((m, 5))
+    kinds = rng.integers(0, 4, m)
+    mats[:, 4] = kinds
+    mats[:, :3] = rng.uniform(0, 1, (m, 3))
+    mats[:, 3] = np.where(kinds == 1, rng.uniform(0, 1, m), rng.uniform(1, 20, m))
+    mats[kinds == 2, 0] = rng.choice([1.5, 1.33, 2.4], (kinds == 2).sum())
+    points = rng.uniform(-50, 50, (m, 3))
+    g["scatter_rays"] = np.concatenate([rng.uniform(-50, 50, (m, 3)), incoming], 1)
+    g["scatter_materials"], g["scatter_points"], g["scatter_normals"] = mats, points, normals
+    g["scatter_out"] = ref.scatter(g["scatter_rays"], mats, points, normals)
+
+    # ---- (5) BVH digests per model (Z-up file order, no transform) and in the model scene
+    for name in PIECES:
+        t = np.fromfile(os.path.join(MODELS, name + ".triangles")).reshape(-1, 9)
+        nodes = ref.construct_triangle_bvh(t)
+        g[f"bvh_sha_{name}"] = np.frombuffer(hashlib.sha256(nodes.tobytes()).digest(), np.uint8)
+        g[f"bvh_count_{name}"] = np.array([len(nodes)])
+    sph = np.concatenate([rng.uniform(-20, 20, (37, 3)), rng.uniform(0.2, 3, (37, 1))], 1)
+    g["sphere_bvh_in"] = sph
+    g["sphere_bvh_out"] = ref.construct_sphere_bvh(sph).view(np.uint8)
+
+    # ---- (6)-(8) the reference's model scene (rook) and the pawn variant
+    for name, size in (("rook", (64, 48)), ("pawn", (64, 36))):
+        scene, cam, aspect = ref.model_scene(os.path.join(MODELS, name + ".triangles"))
+        w_, h_ = size
+        frame = ref.camera_frame(cam, w_ / h_ if name == "pawn" else aspect, w_, h_)
+        g[f"{name}_camera"] = np.frombuffer(bytes(cam), np.float64)
+        g[f"{name}_frame"] = np.frombuffer(bytes(frame), np.uint8)
+        g[f"{name}_rays"] = ref.primary_rays(frame, 0)
+        tri, sphere = scene.primary_hits(frame)
+        g[f"{name}_tri_hits"], g[f"{name}_sphere_hits"] = tri, sphere
+        frame.sample_count = 4
+        accum = scene.render(frame)
+        g[f"{name}_accum4"] = accum
+        g[f"{name}_bgra8"] = ref.tonemap_bgra8(accum, 4)
+        g[f"{name}_sample2_rgb"] = scene.sample_colours(frame, 2)
+        if name == "rook":
+            big = ref.camera_frame(cam, aspect, 600, 600)
+            tri, sphere = scene.primary_hits(big)
+            g["rook600_hits"] = np.array([(tri >= 0).sum(), id_hash(tri), (sphere >= 0).sum()], np.uint64)
+        else:
+            big = ref.camera_frame(cam, 640 / 360, 640, 360)
+            tri, sphere = scene.primary_hits(big)
+            g["pawn640_hits"] = np.array([(tri >= 0).sum(), id_hash(tri), (sphere >= 0).sum()], np.uint64)
+
+    # ---- chess6_row: six pieces, 83,504 triangles (scene arrays rebuilt here from the model files)
+    arrays = chess6_row_arrays(ref)
+    scene = ref.scene_create(arrays)
+    cam = ref.camera_look_at((0.0, 120.0, 260.0), (0.0, 25.0, 0.0), ref.degrees_to_radians(40.0), float(np.float32(0.1)))
+    g["chess6_camera"] = np.frombuffer(bytes(cam), np.float64)
+    g["chess6_triangles_sha"] = np.frombuffer(hashlib.sha256(arrays["triangles"].tobytes()).digest(), np.uint8)
+    g["chess6_bvh_sha"] = np.frombuffer(hashlib.sha256(scene.export()["triangle_bvh"].tobytes()).digest(), np.uint8)
+    small = ref.camera_frame(cam, 640 / 360, 64, 36)
+    tri, sphere = scene.primary_hits(small)
+    g["chess6_tri_hits"], g["chess6_sphere_hits"] = tri, sphere
+    small.sample_count = 4
+    g["chess6_accum4"] = scene.render(small)
+    big = ref.camera_frame(cam, 640 / 360, 640, 360)
+    tri, sphere = scene.primary_hits(big)
+    g["chess6_640_hits"] = np.array([(tri >= 0).sum(), id_hash(tri), (sphere >= 0).sum()], np.uint64)
+
+    path = os.path.join(OUT, "reference_vectors.npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(g)} arrays")
+    print("rook600", g["rook600_hits"], "pawn640", g["pawn640_hits"], "chess6_640", g["chess6_640_hits"])
+
+
+if __name__ == "__main__":
+    main()

@@ -456,6 +456,7 @@ void render_rows(const OrcScene& s, const PtFrame& f, double* accum, int threads
         for (;;) {
             const int row = next_row.fetch_add(1);
             if (row >= f.row_end) break;
+            if (f.shard_count > 1 && ((row - f.row_begin) / PT_ROW_BLOCK) % f.shard_count != f.shard_index) continue;
             // sample-major inside a row: a pixel still receives its samples in ascending order,
             // which is all the frame-by-frame accumulation of src/main.cpp:1001-1036 fixes.
             for (int sample = f.sample_begin; sample < f.sample_begin + f.sample_count; ++sample) {
@@ -601,6 +602,7 @@ void orc_camera_frame(const PtCamera* cam, double aspect_ratio, int width, int h
     frame->width = width; frame->height = height;
     frame->row_begin = 0; frame->row_end = height;
     frame->sample_begin = 0; frame->sample_count = 1;
+    frame->shard_index = 0; frame->shard_count = 1;
     frame->max_bounces = 50;
     frame->aperture = cam->aperture;
     frame->camera_position = PtVec3{pos.x, pos.y, pos.z};

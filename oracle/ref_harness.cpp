@@ -260,6 +260,7 @@ void ref_camera_frame(const PtCamera* cam, double aspect_ratio, int width, int h
     frame->width = width; frame->height = height;
     frame->row_begin = 0; frame->row_end = height;
     frame->sample_begin = 0; frame->sample_count = 1;
+    frame->shard_index = 0; frame->shard_count = 1;
     frame->max_bounces = 50;
     frame->aperture = camera.aperture;
     std::memcpy(&frame->camera_position, &camera_position, 24);
@@ -380,6 +381,7 @@ int ref_render(const RefScene* s, const PtFrame* f, double* accum, int threads) 
         for (;;) {
             const int row = next_row.fetch_add(1);
             if (row >= f->row_end) break;
+            if (f->shard_count > 1 && ((row - f->row_begin) / PT_ROW_BLOCK) % f->shard_count != f->shard_index) continue;
             render_row(*s, *f, row, accum);
         }
     };

@@ -1,0 +1,759 @@
+// The GPU path: scene flattening into HBM, the render / primary-hit / self-test kernels
+// and their C-ABI entry points (pt_scene_create, pt_render, pt_render_device, pt_primary_hits,
+// pt_device_eval).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "pt_device.hpp"
+#include "pt_internal.h"
+
+using namespace ptd;
+
+// =====================================================================================
+// HBM layout
+// =====================================================================================
+//
+// PairNode (128 B, one per inner node of the reference tree): both children's boxes and
+// both child references, so one aligned 128-byte fetch decides the two subtrees and lets
+// the nearer one be entered first.  A child reference >= 0 is a PairNode index; < 0 is
+// ~primitive_index of a leaf.  The root node's own box lives in the TreeRef.
+struct PairNode {
+    double lbox[6];
+    double rbox[6];
+    int32_t left, right;
+    int32_t pad_[6];
+};
+static_assert(sizeof(PairNode) == 128, "PairNode is one 128-byte line");
+
+struct TreeRef {
+    const PairNode* pairs;
+    const PtBvhNode* ref_nodes;   // the reference's own node array, for the exhaustive path
+    int32_t root;                 // child-reference encoding; `count == 0` means "no tree"
+    int32_t count;
+    double root_box[6];
+};
+
+struct DeviceScene {
+    TreeRef tri_tree;
+    const TriRecord* tris;
+    const int32_t* tri_material;
+    TreeRef sph_tree;
+    const double* spheres;        // 4 doubles each
+    const int32_t* sph_material;
+    const PtMaterial* materials;
+    D3 bg0, bg1;
+};
+
+struct Hit { int index; double distance; };
+
+// =====================================================================================
+// Traversal
+// =====================================================================================
+
+struct TriLeaf {
+    const TriRecord* tris;
+    PT_DEV bool test(const Ray& ray, int primitive, double& d) const { return hit_triangle(ray, tris + primitive, d); }
+};
+struct SphLeaf {
+    const double* spheres;
+    PT_DEV bool test(const Ray& ray, int primitive, double& d) const { return hit_sphere(ray, spheres + 4 * primitive, d); }
+};
+
+// The reference's traversal (src/path_tracing.cpp:111-169) evaluated without recursion:
+// every node whose box passes is entered, both children always, and an inner node keeps the
+// strictly smaller child distance; equal distances (two misses included) give a miss.
+// One lane of a wave runs this at a time, with its frames in that wave's LDS slice.
+struct TourFrame { int right; int state; int left_index; double left_distance; };
+
+template <class Leaf>
+__device__ __noinline__ Hit tournament(const Ray& ray, const TreeRef& tree, const Leaf& leaf, TourFrame* frames) {
+    const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+    Hit result{-1, REAL_MAX};
+    int depth = 0;
+    int node = 0;
+    for (;;) {
+        // ---- evaluate `node` downwards until a result exists
+        for (;;) {
+            const PtBvhNode* n = tree.ref_nodes + node;
+            double tmin, tmax;
+            slab_exact(ray.o, inv, &n->aabb.min.x, tmin, tmax);
+            result = Hit{-1, REAL_MAX};
+            if (tmax < 0.0f || tmin > tmax) break;
+            if (n->left == 0 && n->right == 0) {
+                double d;
+                if (leaf.test(ray, n->index, d)) result = Hit{n->index, d};
+                break;
+            }
+            if (depth >= STACK_DEPTH) return Hit{-1, REAL_MAX};   // unreachable: depth is validated at scene creation
+            frames[depth++] = TourFrame{n->right, 0, -1, REAL_MAX};
+            node = n->left;
+        }
+        // ---- hand the result upwards
+        for (;;) {
+            if (depth == 0) return result;
+            TourFrame& f = frames[depth - 1];
+            if (f.state == 0) {
+                f.state = 1;
+                f.left_index = result.index;
+                f.left_distance = result.distance;
+                node = f.right;
+                break;
+            }
+            const Hit l{f.left_index, f.left_distance};
+            if (l.distance < result.distance) result = l;
+            else if (!(result.distance < l.distance)) result = Hit{-1, REAL_MAX};
+            --depth;
+        }
+    }
+}
+
+// Closest-hit search for rays with finite reciprocals: depth-first, nearer child first,
+// subtrees entered beyond `limit` (plus a margin far above any rounding disagreement
+// between a box distance and a primitive distance) skipped.  `tie` reports a second leaf at
+// exactly the winning distance; only then can the answer differ from the tournament's.
+template <class Leaf>
+PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Leaf& leaf, double limit, int* stack /* [level*BLOCK_THREADS] */, bool& tie) {
+    Hit best{-1, REAL_MAX};
+    tie = false;
+    double cut = limit + (1.0e-7 * fabs(limit) + 1.0e-7);
+    {
+        double tmin, tmax;
+        slab_finite(ray.o, inv, tree.root_box[0], tree.root_box[1], tree.root_box[2], tree.root_box[3], tree.root_box[4], tree.root_box[5], tmin, tmax);
+        if (tmax < 0.0f || tmin > tmax || tmin > cut) return best;
+    }
+    auto visit_leaf = [&](int primitive) {
+        double d;
+        if (leaf.test(ray, primitive, d)) {
+            if (d < best.distance) {
+                best = Hit{primitive, d};
+                tie = false;
+                if (d < limit) {
+                    limit = d;
+                    cut = limit + (1.0e-7 * fabs(limit) + 1.0e-7);
+                }
+            } else if (d == best.distance) {
+                tie = true;
+            }
+        }
+    };
+    if (tree.root < 0) {
+        visit_leaf(~tree.root);
+        return best;
+    }
+    int sp = 0;
+    int cur = tree.root;
+    for (;;) {
+        const PairNode* p = tree.pairs + cur;
+        const int lref = p->left, rref = p->right;
+        double lmin, lmax, rmin, rmax;
+        slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
+        slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
+        bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
+        bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+        if (go_l && lref < 0) { visit_leaf(~lref); go_l = false; }
+        if (go_r && rref < 0) { visit_leaf(~rref); go_r = false; }
+        go_l = go_l && !(lmin > cut);
+        go_r = go_r && !(rmin > cut);
+        if (go_l && go_r) {
+            const bool left_first = !(rmin < lmin);
+            stack[sp * BLOCK_THREADS] = left_first ? rref : lref;
+            ++sp;
+            cur = left_first ? lref : rref;
+        } else if (go_l) {
+            cur = lref;
+        } else if (go_r) {
+            cur = rref;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * BLOCK_THREADS];
+        }
+    }
+    return best;
+}
+
+struct BlockShared {
+    int stack[STACK_DEPTH * BLOCK_THREADS];                       // [level][thread]
+    TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];   // one slice per wave
+};
+
+// Closest hit in one tree with the reference's semantics.
+template <class Leaf>
+PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, double limit, BlockShared& sh) {
+    Hit hit{-1, REAL_MAX};
+    if (tree.count == 0) return hit;
+    // A NaN anywhere in the ray makes every primitive test fail (the distance is NaN), whatever
+    // boxes were entered: the reference walks the whole tree and reports a miss.
+    const bool poisoned = any_nan(ray.o) || any_nan(ray.d);
+    const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+    const bool finite = isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z);
+    bool slow = !poisoned && !finite;
+    if (!poisoned && finite) {
+        bool tie;
+        hit = closest_pruned(ray, inv, tree, leaf, limit, sh.stack + threadIdx.x, tie);
+        slow = tie;
+    }
+    // Rare: a reciprocal is infinite (the slab products may be NaN and the exact min/max order
+    // matters) or two leaves tie at the winning distance (the tournament then reports a miss
+    // at their common ancestor).  Lanes take turns through the exact traversal.
+    unsigned long long pending = __ballot(slow);
+    while (pending != 0ull) {
+        const int turn = __ffsll((long long)pending) - 1;
+        pending &= pending - 1ull;
+        if ((int)(threadIdx.x & 63) == turn) {
+            hit = tournament(ray, tree, leaf, sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1));
+        }
+    }
+    return hit;
+}
+
+// =====================================================================================
+// Kernels
+// =====================================================================================
+
+PT_DEV Mat load_material(const PtMaterial* m) { return Mat{m->v[0], m->v[1], m->v[2], m->v[3], m->type}; }
+
+// Wave -> 8x8 pixel tile, lane -> pixel inside the tile.
+PT_DEV bool pixel_of_thread(const FrameParams& f, int& row, int& column) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6);
+    const int tiles_x = (f.width + 7) >> 3;
+    const int tile_row = (int)(wave / tiles_x) * f.shard_count + f.shard_index, tile_col = (int)(wave % tiles_x);
+    row = f.row_begin + tile_row * 8 + (lane >> 3);
+    column = tile_col * 8 + (lane & 7);
+    return row < f.row_end && column < f.width;
+}
+
+// One lane owns one pixel and walks its samples in ascending order, so the per-pixel
+// sum is formed in the order the reference's frame loop forms it (src/main.cpp:1001-1036).
+// Lanes regenerate independently: a lane whose path ended starts its next sample while its
+// neighbours are still bouncing.
+__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(DeviceScene s, FrameParams f, double* __restrict__ accum) {
+    __shared__ BlockShared sh;
+    int row, column;
+    const bool in_image = pixel_of_thread(f, row, column);
+    bool active = in_image && f.sample_count > 0;
+
+    double* px = accum + 4ll * ((long long)row * f.width + column);
+    double sum_b = 0.0, sum_g = 0.0, sum_r = 0.0, sum_n = 0.0;
+    if (active) { sum_b = px[0]; sum_g = px[1]; sum_r = px[2]; sum_n = px[3]; }
+
+    int sample = f.sample_begin;
+    const int sample_end = f.sample_begin + f.sample_count;
+    int bounce = 0;
+    Ray ray{D3{0, 0, 0}, D3{0, 0, 1}};
+    D3 colour{0.0f, 0.0f, 0.0f}, att{1.0f, 1.0f, 1.0f};
+    if (active && f.max_bounces <= 0) {
+        // the reference's bounce loop would not run at all: each sample adds a zero colour and one count
+        for (; sample < sample_end; ++sample) { sum_b += 0.0f; sum_g += 0.0f; sum_r += 0.0f; sum_n += 1.0f; }
+        active = false;
+    }
+    if (active) ray = camera_ray(f, row, column, sample);
+
+    const TriLeaf tri_leaf{s.tris};
+    const SphLeaf sph_leaf{s.spheres};
+
+    while (__any(active)) {
+        if (active) {
+            // src/path_tracing.cpp:177-178
+            const Hit hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, sh);
+            // a triangle beyond the sphere hit cannot win (:183), so the search may stop there
+            const Hit ht = trace_tree(ray, s.tri_tree, tri_leaf, hs.distance, sh);
+            bool ended;
+            if (hs.index != -1 || ht.index != -1) {
+                D3 p, n;
+                int material_index;
+                if (hs.distance < ht.distance) {                                   // :183-194
+                    const double* sp = s.spheres + 4 * hs.index;
+                    p = add3(ray.o, scale3(hs.distance, ray.d));
+                    const double sign = (sp[3] < 0.0f) ? -1.0f : 1.0f;
+                    n = scale3(sign, unit3(sub3(p, D3{sp[0], sp[1], sp[2]})));
+                    material_index = s.sph_material[hs.index];
+                } else {                                                           // :195-206
+                    const TriRecord* t = s.tris + ht.index;
+                    p = add3(ray.o, scale3(ht.distance, ray.d));
+                    n = D3{t->un[0], t->un[1], t->un[2]};
+                    material_index = s.tri_material[ht.index];
+                }
+                const Mat m = load_material(s.materials + material_index);
+                D3 emission{0.0f, 0.0f, 0.0f};                                     // get_emission, src/material.cpp:64-81
+                if (m.type == PT_DIFFUSE_LIGHT) emission = scale3(m.v3, D3{m.v0, m.v1, m.v2});
+                Ray next;
+                const bool valid = scatter(ray, m, p, n, next);
+                colour = add3(colour, mul3(att, emission));                        // :214 / :217
+                if (valid) {
+                    ray = next;
+                    D3 albedo;                                                     // get_colour, src/material.cpp:39-62
+                    if (m.type == PT_LAMBERTIAN || m.type == PT_METAL) albedo = D3{m.v0, m.v1, m.v2};
+                    else if (m.type == PT_DIELECTRIC) albedo = D3{1.0f, 1.0f, 1.0f};
+                    else albedo = D3{0.0f, 0.0f, 0.0f};
+                    att = mul3(att, albedo);                                       // :215
+                    ++bounce;
+                    ended = (bounce >= f.max_bounces);                             // loop exhaustion, :176
+                } else {
+                    ended = true;                                                  // :218
+                }
+            } else {
+                const double t = 0.5f * (ray.d.y + 1.0f);                          // background_gradient, :99-102
+                const D3 bg = add3(scale3(1.0f - t, s.bg0), scale3(t, s.bg1));
+                colour = add3(colour, mul3(att, bg));                              // :221
+                ended = true;
+            }
+            if (ended) {
+                sum_b += colour.z;                                                 // src/main.cpp:117-121
+                sum_g += colour.y;
+                sum_r += colour.x;
+                sum_n += 1.0f;
+                ++sample;
+                if (sample < sample_end) {
+                    ray = camera_ray(f, row, column, sample);
+                    colour = D3{0.0f, 0.0f, 0.0f};
+                    att = D3{1.0f, 1.0f, 1.0f};
+                    bounce = 0;
+                } else {
+                    active = false;
+                }
+            }
+        }
+    }
+    if (in_image && f.sample_count > 0) { px[0] = sum_b; px[1] = sum_g; px[2] = sum_r; px[3] = sum_n; }
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS) void primary_hits_kernel(DeviceScene s, FrameParams f, int* __restrict__ tri_index, int* __restrict__ sph_index) {
+    __shared__ BlockShared sh;
+    int row, column;
+    const bool in_image = pixel_of_thread(f, row, column);
+    Ray ray{D3{0, 0, 0}, D3{0, 0, 1}};
+    if (in_image) ray = camera_ray(f, row, column, f.sample_begin);
+    Hit hs{-1, REAL_MAX}, ht{-1, REAL_MAX};
+    if (in_image) {
+        hs = trace_tree(ray, s.sph_tree, SphLeaf{s.spheres}, REAL_MAX, sh);
+        ht = trace_tree(ray, s.tri_tree, TriLeaf{s.tris}, REAL_MAX, sh);
+    }
+    if (in_image) {
+        const long long i = (long long)row * f.width + column;
+        if (tri_index != nullptr) tri_index[i] = ht.index;
+        if (sph_index != nullptr) sph_index[i] = hs.index;
+    }
+}
+
+// One building block per record; see PT_EVAL_* in the public header for the record shapes.
+__global__ void eval_kernel(int op, const void* __restrict__ in, long long n, void* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* din = (const double*)in;
+    double* dout = (double*)out;
+    switch (op) {
+    case PT_EVAL_NOISE_1D:
+        ((uint32_t*)out)[i] = noise_1d((uint32_t)((const int*)in)[i]);
+        break;
+    case PT_EVAL_NOISE_3D: {
+        const int* v = (const int*)in + 3 * i;
+        ((uint32_t*)out)[i] = noise_3d(v[0], v[1], v[2]);
+        break;
+    }
+    case PT_EVAL_XORSHIFT_REAL: {
+        const uint32_t r = xorshift(((const uint32_t*)in)[i]);
+        ((uint32_t*)out)[4 * i] = r;
+        ((uint32_t*)out)[4 * i + 1] = 0u;
+        dout[2 * i + 1] = real_from_rng(r);
+        break;
+    }
+    case PT_EVAL_RANDOM_UNIT_VECTOR: {
+        const D3 v = random_unit_vector(D3{din[3 * i], din[3 * i + 1], din[3 * i + 2]});
+        dout[3 * i] = v.x; dout[3 * i + 1] = v.y; dout[3 * i + 2] = v.z;
+        break;
+    }
+    case PT_EVAL_RAY_AABB: {
+        const double* r = din + 12 * i;
+        const D3 inv{1.0f / r[3], 1.0f / r[4], 1.0f / r[5]};
+        double tmin, tmax;
+        slab_exact(D3{r[0], r[1], r[2]}, inv, r + 6, tmin, tmax);
+        if (isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z)) {
+            // the fast form must agree wherever it is allowed to run (zeros may differ in sign)
+            double fmin_, fmax_;
+            slab_finite(D3{r[0], r[1], r[2]}, inv, r[6], r[7], r[8], r[9], r[10], r[11], fmin_, fmax_);
+            if (!(fmin_ == tmin && fmax_ == tmax)) { tmin = __builtin_nan(""); tmax = __builtin_nan(""); }
+        }
+        dout[2 * i] = tmin; dout[2 * i + 1] = tmax;
+        break;
+    }
+    case PT_EVAL_RAY_SPHERE: {
+        const double* r = din + 10 * i;
+        double lo, hi;
+        const bool ok = hit_sphere_raw(Ray{D3{r[0], r[1], r[2]}, D3{r[3], r[4], r[5]}}, r + 6, lo, hi);
+        dout[3 * i] = ok ? 1.0 : 0.0; dout[3 * i + 1] = lo; dout[3 * i + 2] = hi;
+        break;
+    }
+    case PT_EVAL_RAY_TRIANGLE: {
+        const double* r = din + 15 * i;
+        // the record is normally precomputed on the host; here it is formed on the device
+        const D3 a{r[6], r[7], r[8]}, b{r[9], r[10], r[11]}, c{r[12], r[13], r[14]};
+        const D3 ab = sub3(b, a), ac = sub3(c, a), nrm = cross3(ab, ac);
+        TriRecord t;
+        t.a[0] = a.x; t.a[1] = a.y; t.a[2] = a.z;
+        t.ab[0] = ab.x; t.ab[1] = ab.y; t.ab[2] = ab.z;
+        t.ac[0] = ac.x; t.ac[1] = ac.y; t.ac[2] = ac.z;
+        t.n[0] = nrm.x; t.n[1] = nrm.y; t.n[2] = nrm.z;
+        t.nn = dot3(nrm, nrm);
+        double d;
+        const bool ok = hit_triangle(Ray{D3{r[0], r[1], r[2]}, D3{r[3], r[4], r[5]}}, &t, d);
+        dout[2 * i] = ok ? 1.0 : 0.0; dout[2 * i + 1] = d;
+        break;
+    }
+    case PT_EVAL_UNIT_NORMAL: {
+        const double* r = din + 9 * i;
+        const D3 a{r[0], r[1], r[2]}, b{r[3], r[4], r[5]}, c{r[6], r[7], r[8]};
+        const D3 un = unit3(cross3(sub3(b, a), sub3(c, a)));
+        dout[3 * i] = un.x; dout[3 * i + 1] = un.y; dout[3 * i + 2] = un.z;
+        break;
+    }
+    case PT_EVAL_SCATTER: {
+        const double* r = din + 17 * i;
+        const Mat m{r[6], r[7], r[8], r[9], (int)r[10]};
+        Ray next;
+        const bool ok = scatter(Ray{D3{r[0], r[1], r[2]}, D3{r[3], r[4], r[5]}}, m, D3{r[11], r[12], r[13]}, D3{r[14], r[15], r[16]}, next);
+        double* o = dout + 7 * i;
+        o[0] = ok ? 1.0 : 0.0;
+        o[1] = next.o.x; o[2] = next.o.y; o[3] = next.o.z;
+        o[4] = next.d.x; o[5] = next.d.y; o[6] = next.d.z;
+        break;
+    }
+    case PT_EVAL_SQRT_DIV:
+        dout[2 * i] = sqrt(din[2 * i]);
+        dout[2 * i + 1] = din[2 * i] / din[2 * i + 1];
+        break;
+    default:
+        break;
+    }
+}
+
+// =====================================================================================
+// Host side: flattening, upload, launches
+// =====================================================================================
+
+namespace {
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        const hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return pt::fail(PT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    ~DeviceBuffer() { if (p != nullptr) (void)hipFree(p); }
+    template <class T> const T* as() const { return static_cast<const T*>(p); }
+};
+
+int upload(DeviceBuffer& buffer, const void* host, size_t bytes) {
+    if (bytes == 0) return PT_OK;
+    HIP_TRY(hipMalloc(&buffer.p, bytes));
+    HIP_TRY(hipMemcpy(buffer.p, host, bytes, hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+// Checks that `nodes` is a well-formed tree in the reference's layout over `primitive_count`
+// leaves (every primitive exactly once) and returns its height (leaf-only tree = 1).
+int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, int* height_out) {
+    if (node_count != 2 * primitive_count - 1) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: %d nodes for %d primitives, expected %d", what, node_count, primitive_count, 2 * primitive_count - 1);
+    std::vector<char> seen_node(node_count, 0), seen_primitive(primitive_count, 0);
+    std::vector<std::pair<int, int>> todo;   // node, depth
+    todo.emplace_back(0, 1);
+    int height = 0;
+    while (!todo.empty()) {
+        const auto [i, depth] = todo.back();
+        todo.pop_back();
+        if (i < 0 || i >= node_count || seen_node[i]) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: node %d is out of range or reached twice", what, i);
+        seen_node[i] = 1;
+        height = std::max(height, depth);
+        const PtBvhNode& n = nodes[i];
+        if (n.left == 0 && n.right == 0) {
+            if (n.index < 0 || n.index >= primitive_count || seen_primitive[n.index]) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: leaf %d names primitive %d (out of range or repeated)", what, i, n.index);
+            seen_primitive[n.index] = 1;
+        } else {
+            if (n.left <= 0 || n.right <= 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: node %d has one child only", what, i);
+            todo.emplace_back(n.right, depth + 1);
+            todo.emplace_back(n.left, depth + 1);
+        }
+    }
+    *height_out = height;
+    return PT_OK;
+}
+
+// Reference tree -> PairNode array (inner nodes numbered in pre-order).
+void flatten_tree(const PtBvhNode* nodes, int node_count, std::vector<PairNode>* pairs, int32_t* root_ref) {
+    std::vector<int32_t> pair_of(node_count, -1);
+    int32_t next = 0;
+    for (int i = 0; i < node_count; ++i) {   // the reference numbers nodes in pre-order already
+        if (!(nodes[i].left == 0 && nodes[i].right == 0)) pair_of[i] = next++;
+    }
+    pairs->assign(next, PairNode{});
+    auto ref_of = [&](int node) -> int32_t {
+        return (nodes[node].left == 0 && nodes[node].right == 0) ? ~nodes[node].index : pair_of[node];
+    };
+    for (int i = 0; i < node_count; ++i) {
+        if (pair_of[i] < 0) continue;
+        PairNode& p = (*pairs)[pair_of[i]];
+        std::memcpy(p.lbox, &nodes[nodes[i].left].aabb, 48);
+        std::memcpy(p.rbox, &nodes[nodes[i].right].aabb, 48);
+        p.left = ref_of(nodes[i].left);
+        p.right = ref_of(nodes[i].right);
+    }
+    *root_ref = ref_of(0);
+}
+
+D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
+
+}  // namespace
+
+struct PtScene {
+    int device = 0;
+    DeviceScene dev{};
+    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material;
+    DeviceBuffer sph_pairs, sph_ref_nodes, spheres, sph_material, materials;
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool timed = false;
+    ~PtScene() {
+        if (start != nullptr) (void)hipEventDestroy(start);
+        if (stop != nullptr) (void)hipEventDestroy(stop);
+    }
+};
+
+namespace {
+
+int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, DeviceBuffer& pairs_buffer,
+               DeviceBuffer& ref_buffer, TreeRef* tree) {
+    int height = 0;
+    int rc = validate_tree(nodes, node_count, primitive_count, what, &height);
+    if (rc != PT_OK) return rc;
+    if (height > STACK_DEPTH) return pt::fail(PT_ERR_UNSUPPORTED, "%s BVH is %d levels deep; the traversal stack holds %d", what, height, STACK_DEPTH);
+    std::vector<PairNode> pairs;
+    int32_t root = 0;
+    flatten_tree(nodes, node_count, &pairs, &root);
+    rc = upload(pairs_buffer, pairs.data(), pairs.size() * sizeof(PairNode));
+    if (rc != PT_OK) return rc;
+    rc = upload(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
+    if (rc != PT_OK) return rc;
+    tree->pairs = pairs_buffer.as<PairNode>();
+    tree->ref_nodes = ref_buffer.as<PtBvhNode>();
+    tree->root = root;
+    tree->count = primitive_count;
+    std::memcpy(tree->root_box, &nodes[0].aabb, 48);
+    return PT_OK;
+}
+
+int check_frame(const PtFrame* f) {
+    if (f == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "null frame");
+    if (f->width < 2 || f->height < 2) return pt::fail(PT_ERR_INVALID_ARGUMENT, "frame %dx%d: width and height must be at least 2", f->width, f->height);
+    if ((long long)f->width * f->height > (1ll << 31) / 4) return pt::fail(PT_ERR_INVALID_ARGUMENT, "frame %dx%d is too large", f->width, f->height);
+    if (f->row_begin < 0 || f->row_end > f->height || f->row_begin > f->row_end) return pt::fail(PT_ERR_INVALID_ARGUMENT, "row range [%d, %d) is outside the %d-row image", f->row_begin, f->row_end, f->height);
+    if (f->sample_begin < 0 || f->sample_count < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "sample range must be non-negative");
+    if (f->max_bounces < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "max_bounces must be non-negative");
+    if (f->shard_count > 1 && (f->shard_index < 0 || f->shard_index >= f->shard_count)) return pt::fail(PT_ERR_INVALID_ARGUMENT, "shard %d of %d does not exist", f->shard_index, f->shard_count);
+    return PT_OK;
+}
+
+FrameParams frame_params(const PtFrame& f) {
+    FrameParams p;
+    p.width = f.width; p.height = f.height;
+    p.row_begin = f.row_begin; p.row_end = f.row_end;
+    p.sample_begin = f.sample_begin; p.sample_count = f.sample_count;
+    p.max_bounces = f.max_bounces; p.pad_ = 0;
+    p.shard_count = f.shard_count > 1 ? f.shard_count : 1;
+    p.shard_index = f.shard_count > 1 ? f.shard_index : 0;
+    p.aperture = f.aperture;
+    p.pos = d3(f.camera_position); p.cx = d3(f.camera_x); p.cy = d3(f.camera_y);
+    p.bl = d3(f.bottom_left); p.sx = d3(f.step_x); p.sy = d3(f.step_y);
+    return p;
+}
+
+unsigned grid_blocks(const PtFrame& f) {
+    const long long tiles_x = (f.width + 7) / 8;
+    const long long blocks_y = (f.row_end - f.row_begin + 7) / 8;
+    const long long shards = f.shard_count > 1 ? f.shard_count : 1;
+    const long long index = f.shard_count > 1 ? f.shard_index : 0;
+    const long long tiles_y = (blocks_y - index + shards - 1) / shards;   // row blocks index, index+shards, ...
+    const long long waves = tiles_x * tiles_y;
+    return static_cast<unsigned>((waves + (BLOCK_THREADS / 64) - 1) / (BLOCK_THREADS / 64));
+}
+
+int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
+    if (frame->row_begin == frame->row_end || frame->sample_count == 0 || grid_blocks(*frame) == 0) return PT_OK;
+    // a path that may not bounce at all contributes nothing but its sample count (the reference's
+    // loop body never runs); the kernel handles that through max_bounces == 0 as well
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipEventRecord(scene->start, stream));
+    hipLaunchKernelGGL(render_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream, scene->dev, frame_params(*frame), accum_device);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(scene->stop, stream));
+    scene->last_stream = stream;
+    scene->timed = true;
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
+    if (d == nullptr || out == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_create: null argument");
+    *out = nullptr;
+    if (d->material_count <= 0 || d->materials == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_create: a scene needs at least one material");
+    if (d->sphere_count < 0 || d->triangle_count < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_create: negative primitive count");
+    for (int i = 0; i < d->material_count; ++i) {
+        if (d->materials[i].type < PT_LAMBERTIAN || d->materials[i].type > PT_DIFFUSE_LIGHT) return pt::fail(PT_ERR_INVALID_ARGUMENT, "material %d has unknown type %d", i, d->materials[i].type);
+    }
+    if (d->sphere_count > 0 && (d->spheres == nullptr || d->sphere_bvh == nullptr || d->sphere_material_indices == nullptr)) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_create: sphere arrays missing");
+    if (d->triangle_count > 0 && (d->triangles == nullptr || d->triangle_bvh == nullptr || d->triangle_material_indices == nullptr)) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_create: triangle arrays missing");
+    for (int i = 0; i < d->sphere_count; ++i) {
+        const int m = d->sphere_material_indices[i];
+        if (m < 0 || m >= d->material_count) return pt::fail(PT_ERR_INVALID_ARGUMENT, "sphere %d names material %d of %d", i, m, d->material_count);
+    }
+    for (int i = 0; i < d->triangle_count; ++i) {
+        const int m = d->triangle_material_indices[i];
+        if (m < 0 || m >= d->material_count) return pt::fail(PT_ERR_INVALID_ARGUMENT, "triangle %d names material %d of %d", i, m, d->material_count);
+    }
+
+    int device_count = 0;
+    HIP_TRY(hipGetDeviceCount(&device_count));
+    if (device < 0 || device >= device_count) return pt::fail(PT_ERR_DEVICE, "device %d requested, %d visible", device, device_count);
+    HIP_TRY(hipSetDevice(device));
+
+    std::unique_ptr<PtScene> scene(new PtScene());
+    scene->device = device;
+    int rc;
+    if (d->triangle_count > 0) {
+        rc = build_tree(d->triangle_bvh, d->triangle_bvh_node_count, d->triangle_count, "triangle", scene->tri_pairs, scene->tri_ref_nodes, &scene->dev.tri_tree);
+        if (rc != PT_OK) return rc;
+        // ray-independent part of the triangle test, same operations as src/geometry.cpp:111-114, :124, :84-90
+        std::vector<TriRecord> records(d->triangle_count);
+        for (int i = 0; i < d->triangle_count; ++i) {
+            const PtTriangle& t = d->triangles[i];
+            using namespace pt;
+            const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
+            const PtVec3 n = cross(ab, ac);
+            const double nn = dot(n, n);
+            const PtVec3 un = (1.0f / std::sqrt(nn)) * n;
+            TriRecord& r = records[i];
+            r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
+            r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
+            r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
+            r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
+            r.nn = nn;
+            r.un[0] = un.x; r.un[1] = un.y; r.un[2] = un.z;
+        }
+        rc = upload(scene->tri_records, records.data(), records.size() * sizeof(TriRecord));
+        if (rc != PT_OK) return rc;
+        rc = upload(scene->tri_material, d->triangle_material_indices, sizeof(int32_t) * d->triangle_count);
+        if (rc != PT_OK) return rc;
+        scene->dev.tris = scene->tri_records.as<TriRecord>();
+        scene->dev.tri_material = scene->tri_material.as<int32_t>();
+    }
+    if (d->sphere_count > 0) {
+        rc = build_tree(d->sphere_bvh, d->sphere_bvh_node_count, d->sphere_count, "sphere", scene->sph_pairs, scene->sph_ref_nodes, &scene->dev.sph_tree);
+        if (rc != PT_OK) return rc;
+        rc = upload(scene->spheres, d->spheres, sizeof(PtSphere) * d->sphere_count);
+        if (rc != PT_OK) return rc;
+        rc = upload(scene->sph_material, d->sphere_material_indices, sizeof(int32_t) * d->sphere_count);
+        if (rc != PT_OK) return rc;
+        scene->dev.spheres = scene->spheres.as<double>();
+        scene->dev.sph_material = scene->sph_material.as<int32_t>();
+    }
+    rc = upload(scene->materials, d->materials, sizeof(PtMaterial) * d->material_count);
+    if (rc != PT_OK) return rc;
+    scene->dev.materials = scene->materials.as<PtMaterial>();
+    scene->dev.bg0 = D3{d->background_gradient_start.r, d->background_gradient_start.g, d->background_gradient_start.b};
+    scene->dev.bg1 = D3{d->background_gradient_end.r, d->background_gradient_end.g, d->background_gradient_end.b};
+    HIP_TRY(hipEventCreate(&scene->start));
+    HIP_TRY(hipEventCreate(&scene->stop));
+    *out = scene.release();
+    return PT_OK;
+}
+
+void pt_scene_destroy(PtScene* scene) {
+    if (scene == nullptr) return;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream) {
+    if (scene == nullptr || accum_device == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_render_device: null argument");
+    const int rc = check_frame(frame);
+    if (rc != PT_OK) return rc;
+    return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream));
+}
+
+int pt_render(PtScene* scene, const PtFrame* frame, double* accum) {
+    if (scene == nullptr || accum == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_render: null argument");
+    int rc = check_frame(frame);
+    if (rc != PT_OK) return rc;
+    if (frame->row_begin == frame->row_end || frame->sample_count == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(scene->device));
+    // only the frame's rows travel: they are contiguous in the row-major buffer
+    const size_t offset = 4ull * frame->row_begin * frame->width;
+    const size_t bytes = 4ull * (frame->row_end - frame->row_begin) * frame->width * sizeof(double);
+    DeviceBuffer rows;
+    HIP_TRY(hipMalloc(&rows.p, bytes));
+    HIP_TRY(hipMemcpy(rows.p, accum + offset, bytes, hipMemcpyHostToDevice));
+    rc = launch_render(scene, frame, static_cast<double*>(rows.p) - offset, nullptr);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(accum + offset, rows.p, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_index, int32_t* sphere_index) {
+    if (scene == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_primary_hits: null scene");
+    const int rc = check_frame(frame);
+    if (rc != PT_OK) return rc;
+    if (frame->row_begin == frame->row_end) return PT_OK;
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t pixels = static_cast<size_t>(frame->width) * frame->height;
+    DeviceBuffer tri, sph;
+    HIP_TRY(hipMalloc(&tri.p, pixels * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&sph.p, pixels * sizeof(int32_t)));
+    hipLaunchKernelGGL(primary_hits_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, nullptr, scene->dev, frame_params(*frame),
+                       static_cast<int*>(tri.p), static_cast<int*>(sph.p));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t offset = static_cast<size_t>(frame->row_begin) * frame->width;
+    const size_t count = static_cast<size_t>(frame->row_end - frame->row_begin) * frame->width;
+    if (triangle_index != nullptr) HIP_TRY(hipMemcpy(triangle_index + offset, static_cast<int32_t*>(tri.p) + offset, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (sphere_index != nullptr) HIP_TRY(hipMemcpy(sphere_index + offset, static_cast<int32_t*>(sph.p) + offset, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_last_render_ms(PtScene* scene, float* ms) {
+    if (scene == nullptr || ms == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_last_render_ms: null argument");
+    if (!scene->timed) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_last_render_ms: nothing has been rendered on this scene");
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipEventSynchronize(scene->stop));
+    HIP_TRY(hipEventElapsedTime(ms, scene->start, scene->stop));
+    return PT_OK;
+}
+
+int pt_device_eval(int32_t device, int32_t op, const void* in, int64_t n, void* out) {
+    static const int IN_BYTES[] = {4, 12, 4, 24, 96, 80, 120, 72, 136, 16};
+    static const int OUT_BYTES[] = {4, 4, 16, 24, 16, 24, 16, 24, 56, 16};
+    if (op < 0 || op > PT_EVAL_SQRT_DIV) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_device_eval: unknown op %d", op);
+    if (in == nullptr || out == nullptr || n < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_device_eval: bad argument");
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(device));
+    DeviceBuffer din, dout;
+    HIP_TRY(hipMalloc(&din.p, static_cast<size_t>(n) * IN_BYTES[op]));
+    HIP_TRY(hipMalloc(&dout.p, static_cast<size_t>(n) * OUT_BYTES[op]));
+    HIP_TRY(hipMemcpy(din.p, in, static_cast<size_t>(n) * IN_BYTES[op], hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, op, din.p, static_cast<long long>(n), dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, static_cast<size_t>(n) * OUT_BYTES[op], hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+// Built-in host scenes.
+//
+// PT_SCENE_MODEL restates the reference's active scene (src/main.cpp:800-840) with the model
+// file as a parameter.  The reference defines no multi-piece scene, so the chess scenes are
+// this library's own: fixed, seedless constructions over the reference's six model files.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+
+#include "pt_internal.h"
+
+using namespace pt;
+
+namespace {
+
+enum Piece { PAWN = 0, ROOK, KNIGHT, BISHOP, QUEEN, KING, PIECE_KINDS };
+const char* const PIECE_FILES[PIECE_KINDS] = {"pawn", "rook", "knight", "bishop", "queen", "king"};
+
+int load_model(const std::string& path, std::vector<PtTriangle>* out) {
+    PtTriangle* data = nullptr;
+    int64_t count = 0;
+    const int rc = pt_load_triangles_file(path.c_str(), &data, &count);
+    if (rc != PT_OK) return rc;
+    out->assign(data, data + count);
+    pt_free(data);
+    if (out->empty()) return fail(PT_ERR_IO, "'%s' holds no triangles", path.c_str());
+    return PT_OK;
+}
+
+// The model files are Z-up; the reference turns them Y-up with a rotation by -pi/2 about x
+// built from float pi (src/main.cpp:808), so the result is not an exact axis swap.
+PtMat3 model_upright() { return rotation(-PI_F / 2.0f, 1.0f, 0.0f, 0.0f); }
+
+void append_transformed(const std::vector<PtTriangle>& model, const PtMat3& m, const PtVec3& offset, int material,
+                        PtHostScene* scene) {
+    for (const PtTriangle& t : model) {
+        scene->triangles.push_back(PtTriangle{transform(m, t.a) + offset, transform(m, t.b) + offset, transform(m, t.c) + offset});
+        scene->triangle_material_indices.push_back(material);
+    }
+}
+
+int finish(PtHostScene* scene) {
+    const int threads = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    if (!scene->spheres.empty()) {
+        std::vector<PtAabb> boxes;
+        for (const PtSphere& s : scene->spheres) boxes.push_back(box_of(s));
+        scene->sphere_bvh.resize(2 * boxes.size() - 1);
+        build_bvh(boxes, scene->sphere_bvh.data(), threads);
+    }
+    if (!scene->triangles.empty()) {
+        std::vector<PtAabb> boxes(scene->triangles.size());
+        for (size_t i = 0; i < boxes.size(); ++i) boxes[i] = box_of(scene->triangles[i]);
+        scene->triangle_bvh.resize(2 * boxes.size() - 1);
+        build_bvh(boxes, scene->triangle_bvh.data(), threads);
+    }
+    return PT_OK;
+}
+
+void set_camera(PtHostScene* scene, PtVec3 position, PtVec3 target, double fov_degrees, double aspect) {
+    pt_camera_look_at(&position, &target, degrees_to_radians(fov_degrees), 0.1f, 0.0, &scene->camera);
+    scene->aspect_ratio = aspect;
+}
+
+// src/main.cpp:800-840
+int build_model(const char* path, PtHostScene* scene) {
+    std::vector<PtTriangle> model;
+    const int rc = load_model(path, &model);
+    if (rc != PT_OK) return rc;
+    scene->materials = {lambertian(6.0f / 255.0f, 4.0f / 255.0f, 3.0f / 255.0f),   // :801 float divisions, then widened
+                        diffuse_light(1.0f, 1.0f, 1.0f, 10.0f)};                    // :802
+    const PtMat3 upright = model_upright();
+    for (const PtTriangle& t : model) {                                             // :809-813
+        scene->triangles.push_back(PtTriangle{transform(upright, t.a), transform(upright, t.b), transform(upright, t.c)});
+    }
+    scene->triangle_material_indices.assign(model.size(), 0);                       // :806
+    scene->spheres = {PtSphere{PtVec3{20.0f, 80.0f, 10.0f}, 20.0f}};                // :817
+    scene->sphere_material_indices = {1};                                           // :818
+    scene->background_start = scene->background_end = PtColour{0.01f, 0.01f, 0.01f};   // :829-830
+    set_camera(scene, PtVec3{0.0f, 150.0f, 150.0f}, PtVec3{0.0f, 0.0f, 0.0f}, 40.0f, 1.0f);   // :833-840, :35
+    return finish(scene);
+}
+
+int load_pieces(const char* dir, std::vector<PtTriangle> (&models)[PIECE_KINDS]) {
+    for (int kind = 0; kind < PIECE_KINDS; ++kind) {
+        const int rc = load_model(std::string(dir) + "/" + PIECE_FILES[kind] + ".triangles", &models[kind]);
+        if (rc != PT_OK) return rc;
+    }
+    return PT_OK;
+}
+
+// One of each piece on a line: piece i (pawn, rook, knight, bishop, queen, king) stands at
+// x = -100 + 40 i.  Materials, light and background are the reference model scene's.
+int build_chess6_row(const char* dir, PtHostScene* scene) {
+    std::vector<PtTriangle> models[PIECE_KINDS];
+    const int rc = load_pieces(dir, models);
+    if (rc != PT_OK) return rc;
+    scene->materials = {lambertian(6.0f / 255.0f, 4.0f / 255.0f, 3.0f / 255.0f), diffuse_light(1.0f, 1.0f, 1.0f, 10.0f)};
+    const PtMat3 upright = model_upright();
+    for (int kind = 0; kind < PIECE_KINDS; ++kind) {
+        append_transformed(models[kind], upright, PtVec3{-100.0f + 40.0f * kind, 0.0f, 0.0f}, 0, scene);
+    }
+    scene->spheres = {PtSphere{PtVec3{20.0f, 80.0f, 10.0f}, 20.0f}};
+    scene->sphere_material_indices = {1};
+    scene->background_start = scene->background_end = PtColour{0.01f, 0.01f, 0.01f};
+    set_camera(scene, PtVec3{0.0f, 120.0f, 260.0f}, PtVec3{0.0f, 25.0f, 0.0f}, 40.0f, 640.0 / 360.0);
+    return finish(scene);
+}
+
+// Material slots of the chess boards.
+enum { M_BLACK = 0, M_LIGHT = 1, M_WHITE = 2, M_BOARD = 3, M_FIRST_MIXED = 4 };
+
+// The 32-piece starting position on 40-unit squares centred on the origin: white on the
+// +z side (towards the camera), black on the -z side and turned to face white.  The board
+// is one quad (two triangles, normal +y) at the lowest vertex of any piece.
+// `material_of(colour, kind)` chooses the material slot of a piece.
+template <class MaterialOf>
+void append_chess_set(const std::vector<PtTriangle> (&models)[PIECE_KINDS], const PtVec3& origin, MaterialOf material_of,
+                      PtHostScene* scene) {
+    static const Piece BACK_RANK[8] = {ROOK, KNIGHT, BISHOP, QUEEN, KING, BISHOP, KNIGHT, ROOK};
+    const PtMat3 white = model_upright();
+    const PtMat3 black = multiply(rotation(PI_F, 0.0f, 1.0f, 0.0f), white);
+    double floor_y = 0.0;
+    const size_t first = scene->triangles.size();
+    for (int file = 0; file < 8; ++file) {
+        const double x = -140.0f + 40.0f * file;
+        append_transformed(models[BACK_RANK[file]], white, origin + PtVec3{x, 0.0f, 140.0f}, material_of(0, BACK_RANK[file]), scene);
+        append_transformed(models[PAWN], white, origin + PtVec3{x, 0.0f, 100.0f}, material_of(0, PAWN), scene);
+        append_transformed(models[PAWN], black, origin + PtVec3{x, 0.0f, -100.0f}, material_of(1, PAWN), scene);
+        append_transformed(models[BACK_RANK[file]], black, origin + PtVec3{x, 0.0f, -140.0f}, material_of(1, BACK_RANK[file]), scene);
+    }
+    for (size_t i = first; i < scene->triangles.size(); ++i) {
+        const PtTriangle& t = scene->triangles[i];
+        floor_y = std::min(floor_y, std::min(t.a.y, std::min(t.b.y, t.c.y)));
+    }
+    const double half = 170.0f, y = floor_y;
+    const PtVec3 p00 = origin + PtVec3{-half, y, -half}, p01 = origin + PtVec3{-half, y, half};
+    const PtVec3 p11 = origin + PtVec3{half, y, half}, p10 = origin + PtVec3{half, y, -half};
+    scene->triangles.push_back(PtTriangle{p00, p01, p11});
+    scene->triangles.push_back(PtTriangle{p11, p10, p00});
+    scene->triangle_material_indices.push_back(M_BOARD);
+    scene->triangle_material_indices.push_back(M_BOARD);
+}
+
+void chess_base_materials(PtHostScene* scene) {
+    scene->materials = {lambertian(6.0f / 255.0f, 4.0f / 255.0f, 3.0f / 255.0f),   // black pieces: the reference's albedo
+                        diffuse_light(1.0f, 1.0f, 1.0f, 10.0f),
+                        lambertian(0.73f, 0.73f, 0.73f),                           // white pieces
+                        lambertian(0.4f, 0.3f, 0.2f)};                             // board
+}
+
+int build_chess32(const char* dir, bool mixed, int grid_n, PtHostScene* scene) {
+    std::vector<PtTriangle> models[PIECE_KINDS];
+    const int rc = load_pieces(dir, models);
+    if (rc != PT_OK) return rc;
+    chess_base_materials(scene);
+    if (mixed) {
+        // every material type on some piece: kind -> slot M_FIRST_MIXED + 2*kind + colour
+        const PtMaterial by_kind[PIECE_KINDS][2] = {
+            {lambertian(0.8f, 0.75f, 0.6f), lambertian(0.15f, 0.1f, 0.1f)},          // pawn
+            {metal(0.9f, 0.9f, 0.9f, 0.0f), metal(0.3f, 0.3f, 0.35f, 0.0f)},         // rook: mirror
+            {metal(0.8f, 0.6f, 0.4f, 0.3f), metal(0.3f, 0.2f, 0.2f, 0.3f)},          // knight: brushed
+            {dielectric(1.5f), dielectric(1.5f)},                                    // bishop: glass
+            {lambertian(0.9f, 0.85f, 0.8f), lambertian(0.3f, 0.1f, 0.3f)},           // queen
+            {metal(0.9f, 0.75f, 0.3f, 0.1f), metal(0.6f, 0.45f, 0.2f, 0.1f)}};       // king: gold
+        for (int kind = 0; kind < PIECE_KINDS; ++kind) {
+            scene->materials.push_back(by_kind[kind][0]);
+            scene->materials.push_back(by_kind[kind][1]);
+        }
+        scene->materials[M_BOARD] = lambertian(0.5f, 0.5f, 0.5f);
+        scene->background_start = PtColour{1.0f, 1.0f, 1.0f};                        // the sky of src/main.cpp:614-615
+        scene->background_end = PtColour{0.5f, 0.7f, 1.0f};
+    } else {
+        scene->background_start = scene->background_end = PtColour{0.01f, 0.01f, 0.01f};
+    }
+    auto material_of = [mixed](int colour, int kind) {
+        if (mixed) return M_FIRST_MIXED + 2 * kind + colour;
+        return colour == 0 ? static_cast<int>(M_WHITE) : static_cast<int>(M_BLACK);
+    };
+    const double pitch = 360.0f;
+    for (int gz = 0; gz < grid_n; ++gz) {
+        for (int gx = 0; gx < grid_n; ++gx) {
+            const PtVec3 origin{pitch * (gx - 0.5 * (grid_n - 1)), 0.0f, pitch * (gz - 0.5 * (grid_n - 1))};
+            append_chess_set(models, origin, material_of, scene);
+        }
+    }
+    scene->spheres = {PtSphere{PtVec3{120.0f * grid_n, 330.0f * grid_n, 60.0f * grid_n}, 140.0f * grid_n}};
+    scene->sphere_material_indices = {M_LIGHT};
+    set_camera(scene, PtVec3{0.0f, 180.0f * grid_n, 330.0f * grid_n}, PtVec3{0.0f, 10.0f, 0.0f}, 40.0f, 16.0 / 9.0);
+    return finish(scene);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_host_scene_build(int32_t kind, const char* path, int32_t param, PtHostScene** out) {
+    if (out == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "pt_host_scene_build: null output");
+    *out = nullptr;
+    std::unique_ptr<PtHostScene> scene(new PtHostScene());
+    int rc;
+    switch (kind) {
+    case PT_SCENE_MODEL:
+        if (path == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "PT_SCENE_MODEL needs a .triangles path");
+        rc = build_model(path, scene.get());
+        break;
+    case PT_SCENE_CHESS6_ROW:
+        if (path == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "chess scenes need the model directory");
+        rc = build_chess6_row(path, scene.get());
+        break;
+    case PT_SCENE_CHESS32:
+    case PT_SCENE_CHESS32_MIXED:
+        if (path == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "chess scenes need the model directory");
+        rc = build_chess32(path, kind == PT_SCENE_CHESS32_MIXED, 1, scene.get());
+        break;
+    case PT_SCENE_CHESS_GRID:
+        if (path == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "chess scenes need the model directory");
+        if (param < 1 || param > 8) return fail(PT_ERR_INVALID_ARGUMENT, "PT_SCENE_CHESS_GRID: grid_n must be in 1..8, got %d", param);
+        rc = build_chess32(path, false, param, scene.get());
+        break;
+    default:
+        return fail(PT_ERR_UNSUPPORTED, "pt_host_scene_build: unknown scene kind %d", kind);
+    }
+    if (rc != PT_OK) return rc;
+    *out = scene.release();
+    return PT_OK;
+}
+
+int pt_host_scene_desc(const PtHostScene* s, PtSceneDesc* d) {
+    if (s == nullptr || d == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "pt_host_scene_desc: null argument");
+    std::memset(d, 0, sizeof(*d));
+    d->materials = s->materials.data();
+    d->material_count = static_cast<int32_t>(s->materials.size());
+    if (!s->spheres.empty()) {
+        d->spheres = s->spheres.data();
+        d->sphere_count = static_cast<int32_t>(s->spheres.size());
+        d->sphere_bvh = s->sphere_bvh.data();
+        d->sphere_bvh_node_count = static_cast<int32_t>(s->sphere_bvh.size());
+        d->sphere_material_indices = s->sphere_material_indices.data();
+    }
+    if (!s->triangles.empty()) {
+        d->triangles = s->triangles.data();
+        d->triangle_count = static_cast<int32_t>(s->triangles.size());
+        d->triangle_bvh = s->triangle_bvh.data();
+        d->triangle_bvh_node_count = static_cast<int32_t>(s->triangle_bvh.size());
+        d->triangle_material_indices = s->triangle_material_indices.data();
+    }
+    d->background_gradient_start = s->background_start;
+    d->background_gradient_end = s->background_end;
+    return PT_OK;
+}
+
+int pt_host_scene_camera(const PtHostScene* s, PtCamera* camera, double* aspect_ratio) {
+    if (s == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "pt_host_scene_camera: null scene");
+    if (camera != nullptr) *camera = s->camera;
+    if (aspect_ratio != nullptr) *aspect_ratio = s->aspect_ratio;
+    return PT_OK;
+}
+
+void pt_host_scene_destroy(PtHostScene* s) { delete s; }
+
+}  // extern "C"

@@ -14,6 +14,8 @@ PT_ERR_DEVICE = 3
 PT_ERR_OUT_OF_MEMORY = 4
 PT_ERR_UNSUPPORTED = 5
 
+PT_ROW_BLOCK = 8
+
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC, PT_DIFFUSE_LIGHT = 0, 1, 2, 3
 
 PT_SCENE_MODEL = 0
@@ -73,6 +75,7 @@ class PtFrame(C.Structure):
         ("aperture", C.c_double),
         ("camera_position", PtVec3), ("camera_x", PtVec3), ("camera_y", PtVec3),
         ("bottom_left", PtVec3), ("step_x", PtVec3), ("step_y", PtVec3),
+        ("shard_index", C.c_int32), ("shard_count", C.c_int32),
     ]
 
     def copy(self, **changes):
@@ -92,7 +95,7 @@ MATERIAL_DTYPE = np.dtype([("v", np.float64, (4,)), ("type", np.int32), ("pad_",
 
 assert C.sizeof(PtVec3) == 24 and C.sizeof(PtMat3) == 72 and C.sizeof(PtCamera) == 128
 assert NODE_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 40
-assert C.sizeof(PtFrame) == 8 * 4 + 8 + 6 * 24
+assert C.sizeof(PtFrame) == 8 * 4 + 8 + 6 * 24 + 8
 assert C.sizeof(PtSceneDesc) == 144
 
 

@@ -1,0 +1,44 @@
+"""Row sharding of one frame over the GPUs of a node and the gather of the accumulation buffer.
+
+The reference parallelises by handing image rows to worker threads (src/main.cpp:1001-1020);
+each pixel is written by exactly one worker.  Here a rank plays the worker: rows are dealt in
+blocks of PT_ROW_BLOCK, block b to rank b % world (PtFrame.shard_index / shard_count), so each
+pixel's samples are still summed by one owner in ascending order and the assembled buffer is
+byte-identical to a single-GPU render.  The only exchange is the final gather of each rank's
+rows to rank 0 (RCCL over xGMI on GPUs, gloo on CPU): 32 B per pixel, once per frame.
+"""
+import torch
+import torch.distributed as dist
+
+from .ctypes_abi import PT_ROW_BLOCK
+
+
+def shard_rows(height, rank, world, row_begin=0):
+    """Row indices (ascending) that `rank` owns out of rows [row_begin, height)."""
+    rows = torch.arange(row_begin, height)
+    block = (rows - row_begin) // PT_ROW_BLOCK
+    return rows[block % world == rank]
+
+
+def gather_rows(accum, height, width, rank, world, dst=0, group=None):
+    """accum: (height, width, 4) float64 tensor holding this rank's rows (others are ignored).
+    After the call rank `dst` holds every rank's rows in place; other ranks are unchanged."""
+    if world == 1:
+        return accum
+    assert accum.shape == (height, width, 4) and accum.dtype == torch.float64
+    counts = [len(shard_rows(height, r, world)) for r in range(world)]
+    longest = max(counts)
+    mine = shard_rows(height, rank, world).to(accum.device)
+    send = torch.zeros((longest, width, 4), dtype=accum.dtype, device=accum.device)
+    send[: len(mine)] = accum.index_select(0, mine)
+    if rank == dst:
+        received = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, received, dst=dst, group=group)
+        for r in range(world):
+            if r == dst:
+                continue
+            rows = shard_rows(height, r, world).to(accum.device)
+            accum.index_copy_(0, rows, received[r][: counts[r]])
+    else:
+        dist.gather(send, None, dst=dst, group=group)
+    return accum

@@ -1,0 +1,286 @@
+"""The HIP path against the reference, through the C ABI, on a real MI355X.
+
+Bar: bit-exact.  Every comparison below is on the raw binary64 bits (any NaN equals any
+NaN) or on integer indices; no tolerance is used anywhere.  Checkers: the committed vectors
+produced by the reference's own code (`golden`), the CPU restatement (`orc`), and, where it
+has been built, the reference build itself (`ref`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, id_hash, same_bits
+from pathtracer_amd import ctypes_abi as abi
+from pathtracer_amd.ctypes_abi import PtFrame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scenes(api, orc):
+    """(host arrays, device scene, checker scene) per scene name, built once."""
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name in ("rook", "pawn", "knight"):
+                host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, name + ".triangles"))
+            else:
+                kind = {"chess6": abi.PT_SCENE_CHESS6_ROW, "chess32": abi.PT_SCENE_CHESS32, "mixed": abi.PT_SCENE_CHESS32_MIXED}[name]
+                host = api.HostScene(kind, MODELS)
+            cache[name] = (host, api.DeviceScene.from_host(host), orc.scene_create(host.arrays()))
+        return cache[name]
+
+    return get
+
+
+# ------------------------------------------------------------------ device arithmetic, one block at a time
+def test_device_hashes(api, golden):
+    out = api.device_eval(abi.PT_EVAL_NOISE_1D, golden["noise1d_in"])
+    assert out[:, 0].tolist() == golden["noise1d_out"].tolist()
+    out = api.device_eval(abi.PT_EVAL_NOISE_3D, golden["noise3d_in"])
+    assert out[:, 0].tolist() == golden["noise3d_out"].tolist()
+    out = api.device_eval(abi.PT_EVAL_XORSHIFT_REAL, golden["xorshift_in"])
+    assert out[:, 0].view(np.uint64).astype(np.uint32).tolist() == golden["xorshift_out"].tolist()
+    assert same_bits(out[:, 1], golden["xorshift_real"])
+
+
+def test_device_sqrt_and_divide_are_correctly_rounded(api):
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.uniform(0, 4, 200000), 10.0 ** rng.uniform(-300, 300, 200000), [0.0, 1.0, 2.0, 4.0, 1e-310, np.inf]])
+    b = np.concatenate([rng.uniform(-3, 3, 200000), 10.0 ** rng.uniform(-150, 150, 200000) * rng.choice([-1, 1], 200000), [3.0, 0.0, -0.0, 7.0, 3.0, 2.0]])
+    out = api.device_eval(abi.PT_EVAL_SQRT_DIV, np.stack([a, b], 1))
+    with np.errstate(all="ignore"):
+        assert same_bits(out[:, 0], np.sqrt(a))
+        assert same_bits(out[:, 1], a / b)
+
+
+def test_device_random_unit_vector(api, golden):
+    assert same_bits(api.device_eval(abi.PT_EVAL_RANDOM_UNIT_VECTOR, golden["ruv_in"]), golden["ruv_out"])
+
+
+def test_device_ray_primitives(api, golden):
+    out = api.device_eval(abi.PT_EVAL_RAY_AABB, np.concatenate([golden["aabb_rays"], golden["aabb_boxes"]], 1))
+    assert same_bits(out, golden["aabb_out"])           # also proves fmin/fmax form == exact form on finite reciprocals
+    out = api.device_eval(abi.PT_EVAL_RAY_SPHERE, np.concatenate([golden["aabb_rays"], golden["sphere_in"]], 1))
+    assert same_bits(out, golden["sphere_out"])
+    out = api.device_eval(abi.PT_EVAL_RAY_TRIANGLE, np.concatenate([golden["tri_rays"], golden["tri_in"]], 1))
+    assert same_bits(out, golden["tri_out"])
+    out = api.device_eval(abi.PT_EVAL_UNIT_NORMAL, golden["tri_in"][:-16])
+    assert same_bits(out, golden["unit_normal_out"])
+
+
+def test_device_scatter(api, golden):
+    records = np.concatenate([golden["scatter_rays"], golden["scatter_materials"], golden["scatter_points"], golden["scatter_normals"]], 1)
+    assert same_bits(api.device_eval(abi.PT_EVAL_SCATTER, records), golden["scatter_out"])
+
+
+# ------------------------------------------------------------------ primary hits: bit-exact triangle ids
+@pytest.mark.parametrize("name,size,key", [("rook", (64, 48), "rook"), ("pawn", (64, 36), "pawn")])
+def test_primary_hits_small(scenes, golden, name, size, key):
+    host, device, _ = scenes(name)
+    frame = PtFrame.from_buffer_copy(golden[f"{key}_frame"].tobytes())
+    tri, sph = device.primary_hits(frame)
+    assert np.array_equal(tri, golden[f"{key}_tri_hits"])
+    assert np.array_equal(sph, golden[f"{key}_sphere_hits"])
+
+
+def test_primary_hit_digests(scenes, golden):
+    host, device, _ = scenes("rook")
+    tri, sph = device.primary_hits(host.frame(600, 600))
+    assert [(tri >= 0).sum(), id_hash(tri), (sph >= 0).sum()] == golden["rook600_hits"].tolist()
+    host, device, _ = scenes("pawn")
+    # the fixture frame uses aspect 640/360 with the model scene's camera (whose own aspect is 1)
+    from pathtracer_amd import api as papi
+    frame = papi.camera_frame(host.camera, 640 / 360, 640, 360)
+    tri, sph = device.primary_hits(frame)
+    assert [(tri >= 0).sum(), id_hash(tri), (sph >= 0).sum()] == golden["pawn640_hits"].tolist()
+    host, device, _ = scenes("chess6")
+    tri, sph = device.primary_hits(host.frame(640, 360))
+    assert [(tri >= 0).sum(), id_hash(tri), (sph >= 0).sum()] == golden["chess6_640_hits"].tolist()
+    tri, sph = device.primary_hits(host.frame(64, 36))
+    assert np.array_equal(tri, golden["chess6_tri_hits"]) and np.array_equal(sph, golden["chess6_sphere_hits"])
+
+
+def test_primary_hits_chess32_vs_checker(scenes):
+    host, device, checker = scenes("chess32")
+    frame = host.frame(320, 180)
+    tri, sph = device.primary_hits(frame)
+    tri_c, sph_c = checker.primary_hits(frame)
+    assert np.array_equal(tri, tri_c) and np.array_equal(sph, sph_c)
+    assert (tri >= 0).mean() > 0.5
+
+
+# ------------------------------------------------------------------ whole paths: accumulation buffers
+@pytest.mark.parametrize("name,key", [("rook", "rook"), ("pawn", "pawn")])
+def test_accumulation_buffer_matches_reference(scenes, golden, name, key):
+    host, device, _ = scenes(name)
+    frame = PtFrame.from_buffer_copy(golden[f"{key}_frame"].tobytes())
+    frame.sample_count = 4
+    accum = device.render(frame)
+    assert same_bits(accum, golden[f"{key}_accum4"])
+
+
+def test_accumulation_buffer_chess6(scenes, golden):
+    host, device, _ = scenes("chess6")
+    accum = device.render(host.frame(64, 36, sample_count=4))
+    assert same_bits(accum, golden["chess6_accum4"])
+
+
+@pytest.mark.parametrize("name,size,spp,bounces", [
+    ("chess32", (160, 90), 4, 50),
+    ("chess32", (96, 54), 3, 16),
+    ("mixed", (160, 90), 4, 16),       # metal, glass, sky: every scatter branch and long paths
+    ("mixed", (64, 36), 2, 50),
+    ("knight", (97, 61), 2, 50),       # sizes that are not multiples of the 8x8 tile
+    ("rook", (33, 17), 1, 1),
+    ("rook", (33, 17), 2, 0),          # no bounce at all: zero colour, counts only
+])
+def test_accumulation_buffer_matches_checker(scenes, name, size, spp, bounces):
+    host, device, checker = scenes(name)
+    frame = host.frame(*size, sample_count=spp, max_bounces=bounces)
+    assert same_bits(device.render(frame), checker.render(frame, threads=8))
+
+
+def test_render_adds_into_the_buffer_and_resumes(scenes):
+    """Progressive accumulation: samples [0,3) then [3,5) on the same buffer == [0,5) at once,
+    and the count channel holds the number of samples (src/main.cpp:117-121)."""
+    host, device, checker = scenes("chess6")
+    whole = device.render(host.frame(80, 45, sample_count=5))
+    parts = device.render(host.frame(80, 45, sample_count=3))
+    device.render(host.frame(80, 45, sample_begin=3, sample_count=2), parts)
+    assert same_bits(whole, parts)
+    assert (whole.reshape(-1, 4)[:, 3] == 5.0).all()
+    assert same_bits(whole, checker.render(host.frame(80, 45, sample_count=5), threads=8))
+
+
+def test_row_ranges_tile_the_image(scenes):
+    """Rows are independent (the reference's work queue hands them out one at a time): any
+    split into row ranges gives the bytes of the full render, and rows outside are untouched."""
+    host, device, _ = scenes("chess6")
+    full = device.render(host.frame(72, 41, sample_count=2))
+    pieces = np.zeros_like(full)
+    for begin, end in [(0, 5), (5, 6), (6, 30), (30, 41)]:
+        device.render(host.frame(72, 41, sample_count=2, row_begin=begin, row_end=end), pieces)
+    assert same_bits(full, pieces)
+    only = device.render(host.frame(72, 41, sample_count=2, row_begin=9, row_end=10))
+    rows = only.reshape(41, 72, 4)
+    assert (rows[:9] == 0).all() and (rows[10:] == 0).all() and same_bits(rows[9], full.reshape(41, 72, 4)[9])
+    # empty ranges are legal no-ops
+    assert (device.render(host.frame(72, 41, row_begin=7, row_end=7)) == 0).all()
+    assert (device.render(host.frame(72, 41, sample_count=0)) == 0).all()
+
+
+def test_full_size_properties(scenes, api):
+    """1920x1080 chess set (the benchmark configuration) through properties that need no CPU
+    render: sample-range additivity, the count channel, finiteness, and a CPU spot check of
+    a few rows."""
+    import torch
+    host, device, checker = scenes("chess32")
+    w, h = 1920, 1080
+    buf = torch.zeros(4 * w * h, dtype=torch.float64, device="cuda:0")
+    device.render_device(host.frame(w, h, sample_count=2), buf.data_ptr())
+    device.render_device(host.frame(w, h, sample_begin=2, sample_count=1), buf.data_ptr())
+    torch.cuda.synchronize()
+    once = torch.zeros_like(buf)
+    device.render_device(host.frame(w, h, sample_count=3), once.data_ptr())
+    torch.cuda.synchronize()
+    assert device.last_render_ms() > 0
+    assert torch.equal(buf.view(torch.int64), once.view(torch.int64))
+    image = once.cpu().numpy().reshape(h, w, 4)
+    assert (image[..., 3] == 3.0).all() and np.isfinite(image).all() and (image[..., :3] >= 0).all()
+    rows = (0, 397, 1079)
+    for row in rows:
+        expect = checker.render(host.frame(w, h, sample_count=3, row_begin=row, row_end=row + 1), threads=8)
+        assert same_bits(image[row], expect.reshape(h, w, 4)[row])
+
+
+def test_live_reference_build(scenes, ref, api):
+    """Where the reference's own build is present: its render of its own scene, bit for bit."""
+    host, device, _ = scenes("rook")
+    scene, cam, aspect = ref.model_scene(os.path.join(MODELS, "rook.triangles"))
+    frame = host.frame(128, 128, sample_count=3)
+    assert same_bits(device.render(frame), scene.render(frame, threads=8))
+    tri, sph = device.primary_hits(frame)
+    tri_r, sph_r = scene.primary_hits(frame)
+    assert np.array_equal(tri, tri_r) and np.array_equal(sph, sph_r)
+
+
+# ------------------------------------------------------------------ edge cases the traversal has special paths for
+def test_tied_leaves_report_a_miss_like_the_reference(api, orc):
+    """Two identical triangles tie at every hit; the reference's tournament then reports a
+    miss at their common ancestor (src/path_tracing.cpp:161-167), and rays see what lies behind."""
+    front = [-10.0, -10.0, 0.0, 10.0, -10.0, 0.0, 0.0, 10.0, 0.0]
+    back = [-30.0, -30.0, -5.0, 30.0, -30.0, -5.0, 0.0, 30.0, -5.0]
+    far = [-60.0, -60.0, -9.0, 60.0, -60.0, -9.0, 0.0, 60.0, -9.0]
+    triangles = np.array([front, back, front, far])
+    materials = np.zeros(2, abi.MATERIAL_DTYPE)
+    materials[0]["v"] = [0.5, 0.6, 0.7, 0.0]
+    materials[1]["v"] = [1.0, 1.0, 1.0, 4.0]
+    materials[1]["type"] = abi.PT_DIFFUSE_LIGHT
+    arrays = {"materials": materials, "triangles": triangles, "triangle_material_indices": np.array([0, 1, 0, 0], np.int32),
+              "spheres": np.zeros((0, 4)), "sphere_material_indices": np.zeros(0, np.int32),
+              "background": np.array([[0.2, 0.3, 0.4], [0.9, 0.8, 0.7]])}
+    arrays["triangle_bvh"] = api.construct_triangle_bvh(triangles)
+    from oracle.bindings import make_desc
+    desc, keep = make_desc(arrays)
+    device = api.DeviceScene(desc, keepalive=keep)
+    checker = orc.scene_create(arrays)
+    cam = api.camera_look_at((0.0, 0.0, 40.0), (0.0, 0.0, 0.0), 0.8, 0.0)
+    frame = api.camera_frame(cam, 1.0, 48, 48, sample_count=2)
+    tri, _ = device.primary_hits(frame)
+    tri_c, _ = checker.primary_hits(frame)
+    assert np.array_equal(tri, tri_c)
+    assert not np.isin(tri, [0, 2]).any() and (tri == 1).any()      # the duplicated triangle is never reported
+    assert same_bits(device.render(frame), checker.render(frame))
+
+
+def test_axis_parallel_rays_take_the_exact_path(api, orc):
+    """aperture 0 and a camera on an axis give primary rays with exactly zero direction
+    components: infinite reciprocals, 0 * inf in the slab test, exact min/max order matters."""
+    rng = np.random.default_rng(5)
+    base = rng.integers(-8, 8, (400, 1, 3)).astype(float)
+    triangles = (base + rng.integers(0, 3, (400, 3, 3))).reshape(-1, 9)
+    materials = np.zeros(1, abi.MATERIAL_DTYPE)
+    materials[0]["v"] = [0.7, 0.7, 0.7, 0.0]
+    arrays = {"materials": materials, "triangles": triangles, "triangle_material_indices": np.zeros(len(triangles), np.int32),
+              "spheres": np.array([[0.0, 0.0, 0.0, 2.0]]), "sphere_material_indices": np.zeros(1, np.int32),
+              "background": np.array([[1.0, 1.0, 1.0], [0.5, 0.7, 1.0]])}
+    arrays["triangle_bvh"] = api.construct_triangle_bvh(triangles)
+    arrays["sphere_bvh"] = api.construct_sphere_bvh(arrays["spheres"])
+    from oracle.bindings import make_desc
+    desc, keep = make_desc(arrays)
+    device = api.DeviceScene(desc, keepalive=keep)
+    checker = orc.scene_create(arrays)
+    frame = api.camera_frame(api.camera_look_at((0.0, 0.0, 30.0), (0.0, 0.0, 0.0), 0.9, 0.0), 1.0, 33, 33, sample_count=2)
+    # a fan of rays in the plane x = 3 of the integer lattice the triangles live on: the x
+    # component of every direction is exactly zero and (box.x - origin.x) is often exactly zero
+    frame.camera_x.x, frame.camera_x.y, frame.camera_x.z = 1.0, 0.0, 0.0
+    frame.camera_y.x, frame.camera_y.y, frame.camera_y.z = 0.0, 1.0, 0.0
+    frame.step_x.x, frame.step_x.y, frame.step_x.z = 0.0, 0.0, 0.0
+    frame.step_y.x, frame.step_y.y, frame.step_y.z = 0.0, 32.0, 0.0
+    frame.bottom_left.x, frame.bottom_left.y, frame.bottom_left.z = 3.0, -14.0, 0.0
+    frame.camera_position.x, frame.camera_position.y, frame.camera_position.z = 3.0, 2.0, 30.0
+    tri, sph = device.primary_hits(frame)
+    tri_c, sph_c = checker.primary_hits(frame)
+    assert np.array_equal(tri, tri_c) and np.array_equal(sph, sph_c)
+    assert same_bits(device.render(frame), checker.render(frame))
+
+
+def test_scene_create_validates_trees(api):
+    host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, "rook.triangles"))
+    arrays = host.arrays()
+    from oracle.bindings import make_desc
+    nodes = arrays["triangle_bvh"].copy()
+    nodes[5]["left"] = 10 ** 6
+    desc, keep = make_desc({**arrays, "triangle_bvh": nodes})
+    with pytest.raises(api.PathTracerError) as e:
+        api.DeviceScene(desc, keepalive=keep)
+    assert e.value.code == abi.PT_ERR_INVALID_ARGUMENT
+    desc, keep = make_desc({**arrays, "triangle_bvh": arrays["triangle_bvh"][:-2]})
+    with pytest.raises(api.PathTracerError):
+        api.DeviceScene(desc, keepalive=keep)
+    with pytest.raises(api.PathTracerError):
+        api.DeviceScene.from_host(host, device=99)

@@ -1,0 +1,164 @@
+"""Host side of libpathtracer_amd.so: the entry points kept from the reference (model loading,
+BVH build, camera, scenes, image output), error behaviour and the exported C ABI.  CPU only:
+nothing here touches a GPU.
+"""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, ROOT, same_bits
+from pathtracer_amd import ctypes_abi as abi
+
+PIECES = ["pawn", "rook", "knight", "bishop", "queen", "king"]
+COUNTS = {"pawn": 12286, "rook": 6716, "knight": 19972, "bishop": 15104, "queen": 14662, "king": 14764}
+
+
+def test_library_exports_every_declared_symbol(api):
+    header = open(os.path.join(ROOT, "include", "pathtracer_amd.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    for name in declared:
+        assert getattr(api.lib(), name) is not None
+
+
+def test_load_triangles_file(api, tmp_path):
+    for name, count in COUNTS.items():
+        path = os.path.join(MODELS, name + ".triangles")
+        triangles = api.load_triangles_file(path)
+        assert triangles.shape == (count, 9)
+        assert triangles.tobytes() == open(path, "rb").read()
+    # round trip through save_triangles_file
+    out = tmp_path / "copy.triangles"
+    api.save_triangles_file(str(out), triangles)
+    assert out.read_bytes() == triangles.tobytes()
+    # empty file: zero triangles, not an error (size % 72 == 0 holds)
+    empty = tmp_path / "empty.triangles"
+    empty.write_bytes(b"")
+    assert api.load_triangles_file(str(empty)).shape == (0, 9)
+
+
+def test_load_triangles_file_errors(api, tmp_path):
+    with pytest.raises(api.PathTracerError) as e:
+        api.load_triangles_file(str(tmp_path / "missing.triangles"))
+    assert e.value.code == abi.PT_ERR_IO
+    ragged = tmp_path / "ragged.triangles"
+    ragged.write_bytes(b"\0" * 100)          # the reference asserts size % sizeof(Triangle) == 0
+    with pytest.raises(api.PathTracerError) as e:
+        api.load_triangles_file(str(ragged))
+    assert e.value.code == abi.PT_ERR_IO and "72-byte" in str(e.value)
+
+
+def test_bvh_build_matches_reference_digests(api, golden):
+    for name in PIECES:
+        triangles = api.load_triangles_file(os.path.join(MODELS, name + ".triangles"))
+        nodes = api.construct_triangle_bvh(triangles)
+        assert hashlib.sha256(nodes.tobytes()).digest() == golden[f"bvh_sha_{name}"].tobytes(), name
+    assert api.construct_sphere_bvh(golden["sphere_bvh_in"]).tobytes() == golden["sphere_bvh_out"].tobytes()
+
+
+def test_bvh_build_structure_and_edge_cases(api, orc):
+    rng = np.random.default_rng(3)
+    # one primitive: a single leaf node
+    one = rng.uniform(-1, 1, (1, 9))
+    nodes = api.construct_triangle_bvh(one)
+    assert len(nodes) == 1 and nodes[0]["left"] == 0 and nodes[0]["right"] == 0 and nodes[0]["index"] == 0
+    # many equal keys: topology depends on how std::sort orders ties; must equal the checker's
+    grid = np.repeat(rng.integers(-3, 3, (300, 1, 3)).astype(float), 3, axis=1) + rng.integers(0, 2, (300, 3, 3))
+    tri = grid.reshape(-1, 9)
+    assert api.construct_triangle_bvh(tri).tobytes() == orc.construct_triangle_bvh(tri).tobytes()
+    # the threaded build (>= 32768 primitives) lands every node in the same slot as the serial one
+    big = rng.uniform(-100, 100, (40000, 9))
+    assert api.construct_triangle_bvh(big).tobytes() == orc.construct_triangle_bvh(big).tobytes()
+    with pytest.raises(api.PathTracerError):
+        api.construct_triangle_bvh(np.zeros((0, 9)))
+
+
+def test_camera_and_frame(api, orc, golden):
+    cam = api.camera_look_at((0.0, 150.0, 150.0), (0.0, 0.0, 0.0), orc.degrees_to_radians(40.0), float(np.float32(0.1)))
+    assert bytes(cam) == golden["rook_camera"].tobytes()
+    assert bytes(api.camera_frame(cam, 1.0, 64, 48)) == golden["rook_frame"].tobytes()
+    assert bytes(api.camera_frame(cam, 64 / 36, 64, 36)) == golden["pawn_frame"].tobytes()
+    for angle, axis in [(0.3, (1, 2, 3)), (-1.25, (0, 0, 1)), (float(np.float32(np.pi)), (0, 1, 0))]:
+        assert same_bits(api.rotation_matrix(angle, *axis), orc.rotation_matrix(angle, *axis))
+    with pytest.raises(api.PathTracerError):
+        api.camera_frame(cam, 1.0, 1, 48)       # u = column / (width - 1)
+
+
+def test_model_scene_is_the_reference_scene(api, orc, golden):
+    for name in ("rook", "pawn"):
+        host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, name + ".triangles"))
+        checker, cam, aspect = orc.model_scene(os.path.join(MODELS, name + ".triangles"))
+        assert bytes(host.camera) == bytes(cam) == golden[f"{name}_camera"].tobytes()
+        assert host.aspect_ratio == aspect == 1.0
+        ours, theirs = host.arrays(), checker.export()
+        for key in theirs:
+            assert ours[key].tobytes() == theirs[key].tobytes(), (name, key)
+
+
+def test_chess_scenes(api, golden):
+    six = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
+    arrays = six.arrays()
+    assert len(arrays["triangles"]) == sum(COUNTS.values()) == 83504
+    assert hashlib.sha256(arrays["triangles"].tobytes()).digest() == golden["chess6_triangles_sha"].tobytes()
+    assert hashlib.sha256(arrays["triangle_bvh"].tobytes()).digest() == golden["chess6_bvh_sha"].tobytes()
+    assert bytes(six.camera) == golden["chess6_camera"].tobytes()
+
+    full = api.HostScene(abi.PT_SCENE_CHESS32, MODELS)
+    arrays = full.arrays()
+    expect = 16 * COUNTS["pawn"] + 4 * (COUNTS["rook"] + COUNTS["knight"] + COUNTS["bishop"]) + 2 * (COUNTS["queen"] + COUNTS["king"]) + 2
+    assert len(arrays["triangles"]) == expect == 422598
+    assert len(arrays["triangle_bvh"]) == 2 * expect - 1
+    assert set(arrays["triangle_material_indices"].tolist()) == {0, 2, 3}
+    assert (arrays["triangle_material_indices"] == 2).sum() == (arrays["triangle_material_indices"] == 0).sum()
+    mixed = api.HostScene(abi.PT_SCENE_CHESS32_MIXED, MODELS).arrays()
+    assert mixed["triangles"].tobytes() == arrays["triangles"].tobytes()
+    used = set(mixed["materials"]["type"][np.unique(mixed["triangle_material_indices"])].tolist())
+    assert used == {abi.PT_LAMBERTIAN, abi.PT_METAL, abi.PT_DIELECTRIC}
+
+    with pytest.raises(api.PathTracerError) as e:
+        api.HostScene(abi.PT_SCENE_CHESS32, str(ROOT))        # no model files there
+    assert e.value.code == abi.PT_ERR_IO
+    with pytest.raises(api.PathTracerError) as e:
+        api.HostScene(99)
+    assert e.value.code == abi.PT_ERR_UNSUPPORTED
+
+
+def test_tonemap_and_pixel_file(api, golden, tmp_path):
+    for name in ("rook", "pawn"):
+        assert np.array_equal(api.tonemap_bgra8(golden[f"{name}_accum4"], 4), golden[f"{name}_bgra8"])
+    # clamp at 1, zero stays zero, alpha always 255
+    accum = np.array([0.0, 4.0, 400.0, 4.0, 1.0, 2.25, 0.25, 4.0])
+    assert api.tonemap_bgra8(accum, 4).tolist() == [0, 255, 255, 255, 127, 191, 63, 255]
+    bgra = golden["rook_bgra8"]
+    path = tmp_path / "pixels.data"
+    api.write_pixel_data_file(str(path), bgra)
+    data = np.frombuffer(path.read_bytes(), np.uint8).reshape(-1, 4)
+    assert np.array_equal(data[:, [2, 1, 0, 3]], bgra.reshape(-1, 4))     # RGBA on disk, rows untouched (bottom-up)
+    with pytest.raises(api.PathTracerError):
+        api.tonemap_bgra8(accum, 0)
+
+
+def test_scene_create_rejects_bad_input_without_a_gpu(api):
+    from oracle.bindings import make_desc
+    host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, "rook.triangles"))
+    arrays = host.arrays()
+    handle = C.c_void_p()
+
+    def create(**changes):
+        desc, keep = make_desc({**arrays, **changes})
+        code = api.lib().pt_scene_create(C.byref(desc), 0, C.byref(handle))
+        return code, api.lib().pt_last_error().decode()
+
+    bad = arrays["triangle_material_indices"].copy()
+    bad[17] = 5
+    code, message = create(triangle_material_indices=bad)
+    assert code == abi.PT_ERR_INVALID_ARGUMENT and "triangle 17" in message
+    mats = arrays["materials"].copy()
+    mats[0]["type"] = 9
+    code, message = create(materials=mats)
+    assert code == abi.PT_ERR_INVALID_ARGUMENT and "unknown type" in message
+    assert api.lib().pt_scene_create(None, 0, C.byref(handle)) == abi.PT_ERR_INVALID_ARGUMENT
