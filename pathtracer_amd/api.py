@@ -40,6 +40,13 @@ def lib():
         if not os.path.exists(LIBRARY_PATH):
             raise FileNotFoundError(f"{LIBRARY_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
                                     "there is no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm carries its own libamdhip64.so (SONAME
+        # libamdhip64.so.7).  Loaded first, it satisfies this library's dependency by SONAME; loaded
+        # second, the loader would bring in a second runtime that finds no usable GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         dll = C.CDLL(LIBRARY_PATH)
         dll.pt_last_error.restype = C.c_char_p
         dll.pt_free.restype = None
