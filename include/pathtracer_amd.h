@@ -208,6 +208,11 @@ int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_inde
  * launch has finished).  Not in the reference: measurement only. */
 int pt_last_render_ms(PtScene* scene, float* ms);
 
+/* Profiling aid, not in the reference: with PT_STATS=1 in the environment the wavefront kernel
+ * counts its phases; out[0..7] = node phases, lanes active in them, leaf phases, lanes, shade
+ * phases, lanes, loop iterations, paths started (all summed over waves). */
+int pt_last_render_stats(PtScene* scene, uint64_t* out);
+
 /* Device self-test hook: evaluates one device-side building block of the path
  * on `n` packed input records and copies the results back (host pointers).
  * Not in the reference; it exists so the device arithmetic can be checked

@@ -20,7 +20,7 @@ EXPORTS = [
     "pt_construct_sphere_bvh", "pt_rotation_matrix", "pt_look_at_matrix", "pt_camera_look_at", "pt_camera_frame",
     "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8",
     "pt_write_pixel_data_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
-    "pt_primary_hits", "pt_last_render_ms", "pt_device_eval",
+    "pt_primary_hits", "pt_last_render_ms", "pt_last_render_stats", "pt_device_eval",
 ]
 
 
@@ -73,6 +73,7 @@ def lib():
         dll.pt_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        dll.pt_last_render_stats.argtypes = [C.c_void_p, C.c_void_p]
         dll.pt_device_eval.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = dll
     return _lib
@@ -228,6 +229,12 @@ class DeviceScene:
         ms = C.c_float()
         check(lib().pt_last_render_ms(self.handle, C.byref(ms)))
         return ms.value
+
+    def last_render_stats(self):
+        out = np.zeros(8, np.uint64)
+        check(lib().pt_last_render_stats(self.handle, ptr(out)))
+        names = ["node_phases", "node_lanes", "leaf_phases", "leaf_lanes", "shade_phases", "shade_lanes", "loops", "paths"]
+        return dict(zip(names, out.tolist()))
 
     def primary_hits(self, frame):
         tri = np.full((frame.height, frame.width), -2, np.int32)

@@ -4,218 +4,21 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
 
-#include "pt_device.hpp"
+#include "pt_wavefront.hpp"
 #include "pt_internal.h"
 
 using namespace ptd;
 
 // =====================================================================================
-// HBM layout
-// =====================================================================================
-//
-// PairNode (128 B, one per inner node of the reference tree): both children's boxes and
-// both child references, so one aligned 128-byte fetch decides the two subtrees and lets
-// the nearer one be entered first.  A child reference >= 0 is a PairNode index; < 0 is
-// ~primitive_index of a leaf.  The root node's own box lives in the TreeRef.
-struct PairNode {
-    double lbox[6];
-    double rbox[6];
-    int32_t left, right;
-    int32_t pad_[6];
-};
-static_assert(sizeof(PairNode) == 128, "PairNode is one 128-byte line");
-
-struct TreeRef {
-    const PairNode* pairs;
-    const PtBvhNode* ref_nodes;   // the reference's own node array, for the exhaustive path
-    int32_t root;                 // child-reference encoding; `count == 0` means "no tree"
-    int32_t count;
-    double root_box[6];
-};
-
-struct DeviceScene {
-    TreeRef tri_tree;
-    const TriRecord* tris;
-    const int32_t* tri_material;
-    TreeRef sph_tree;
-    const double* spheres;        // 4 doubles each
-    const int32_t* sph_material;
-    const PtMaterial* materials;
-    D3 bg0, bg1;
-};
-
-struct Hit { int index; double distance; };
-
-// =====================================================================================
-// Traversal
-// =====================================================================================
-
-struct TriLeaf {
-    const TriRecord* tris;
-    PT_DEV bool test(const Ray& ray, int primitive, double& d) const { return hit_triangle(ray, tris + primitive, d); }
-};
-struct SphLeaf {
-    const double* spheres;
-    PT_DEV bool test(const Ray& ray, int primitive, double& d) const { return hit_sphere(ray, spheres + 4 * primitive, d); }
-};
-
-// The reference's traversal (src/path_tracing.cpp:111-169) evaluated without recursion:
-// every node whose box passes is entered, both children always, and an inner node keeps the
-// strictly smaller child distance; equal distances (two misses included) give a miss.
-// One lane of a wave runs this at a time, with its frames in that wave's LDS slice.
-struct TourFrame { int right; int state; int left_index; double left_distance; };
-
-template <class Leaf>
-__device__ __noinline__ Hit tournament(const Ray& ray, const TreeRef& tree, const Leaf& leaf, TourFrame* frames) {
-    const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
-    Hit result{-1, REAL_MAX};
-    int depth = 0;
-    int node = 0;
-    for (;;) {
-        // ---- evaluate `node` downwards until a result exists
-        for (;;) {
-            const PtBvhNode* n = tree.ref_nodes + node;
-            double tmin, tmax;
-            slab_exact(ray.o, inv, &n->aabb.min.x, tmin, tmax);
-            result = Hit{-1, REAL_MAX};
-            if (tmax < 0.0f || tmin > tmax) break;
-            if (n->left == 0 && n->right == 0) {
-                double d;
-                if (leaf.test(ray, n->index, d)) result = Hit{n->index, d};
-                break;
-            }
-            if (depth >= STACK_DEPTH) return Hit{-1, REAL_MAX};   // unreachable: depth is validated at scene creation
-            frames[depth++] = TourFrame{n->right, 0, -1, REAL_MAX};
-            node = n->left;
-        }
-        // ---- hand the result upwards
-        for (;;) {
-            if (depth == 0) return result;
-            TourFrame& f = frames[depth - 1];
-            if (f.state == 0) {
-                f.state = 1;
-                f.left_index = result.index;
-                f.left_distance = result.distance;
-                node = f.right;
-                break;
-            }
-            const Hit l{f.left_index, f.left_distance};
-            if (l.distance < result.distance) result = l;
-            else if (!(result.distance < l.distance)) result = Hit{-1, REAL_MAX};
-            --depth;
-        }
-    }
-}
-
-// Closest-hit search for rays with finite reciprocals: depth-first, nearer child first,
-// subtrees entered beyond `limit` (plus a margin far above any rounding disagreement
-// between a box distance and a primitive distance) skipped.  `tie` reports a second leaf at
-// exactly the winning distance; only then can the answer differ from the tournament's.
-template <class Leaf>
-PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Leaf& leaf, double limit, int* stack /* [level*BLOCK_THREADS] */, bool& tie) {
-    Hit best{-1, REAL_MAX};
-    tie = false;
-    double cut = limit + (1.0e-7 * fabs(limit) + 1.0e-7);
-    {
-        double tmin, tmax;
-        slab_finite(ray.o, inv, tree.root_box[0], tree.root_box[1], tree.root_box[2], tree.root_box[3], tree.root_box[4], tree.root_box[5], tmin, tmax);
-        if (tmax < 0.0f || tmin > tmax || tmin > cut) return best;
-    }
-    auto visit_leaf = [&](int primitive) {
-        double d;
-        if (leaf.test(ray, primitive, d)) {
-            if (d < best.distance) {
-                best = Hit{primitive, d};
-                tie = false;
-                if (d < limit) {
-                    limit = d;
-                    cut = limit + (1.0e-7 * fabs(limit) + 1.0e-7);
-                }
-            } else if (d == best.distance) {
-                tie = true;
-            }
-        }
-    };
-    if (tree.root < 0) {
-        visit_leaf(~tree.root);
-        return best;
-    }
-    int sp = 0;
-    int cur = tree.root;
-    for (;;) {
-        const PairNode* p = tree.pairs + cur;
-        const int lref = p->left, rref = p->right;
-        double lmin, lmax, rmin, rmax;
-        slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
-        slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
-        bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
-        bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
-        if (go_l && lref < 0) { visit_leaf(~lref); go_l = false; }
-        if (go_r && rref < 0) { visit_leaf(~rref); go_r = false; }
-        go_l = go_l && !(lmin > cut);
-        go_r = go_r && !(rmin > cut);
-        if (go_l && go_r) {
-            const bool left_first = !(rmin < lmin);
-            stack[sp * BLOCK_THREADS] = left_first ? rref : lref;
-            ++sp;
-            cur = left_first ? lref : rref;
-        } else if (go_l) {
-            cur = lref;
-        } else if (go_r) {
-            cur = rref;
-        } else {
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * BLOCK_THREADS];
-        }
-    }
-    return best;
-}
-
-struct BlockShared {
-    int stack[STACK_DEPTH * BLOCK_THREADS];                       // [level][thread]
-    TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];   // one slice per wave
-};
-
-// Closest hit in one tree with the reference's semantics.
-template <class Leaf>
-PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, double limit, BlockShared& sh) {
-    Hit hit{-1, REAL_MAX};
-    if (tree.count == 0) return hit;
-    // A NaN anywhere in the ray makes every primitive test fail (the distance is NaN), whatever
-    // boxes were entered: the reference walks the whole tree and reports a miss.
-    const bool poisoned = any_nan(ray.o) || any_nan(ray.d);
-    const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
-    const bool finite = isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z);
-    bool slow = !poisoned && !finite;
-    if (!poisoned && finite) {
-        bool tie;
-        hit = closest_pruned(ray, inv, tree, leaf, limit, sh.stack + threadIdx.x, tie);
-        slow = tie;
-    }
-    // Rare: a reciprocal is infinite (the slab products may be NaN and the exact min/max order
-    // matters) or two leaves tie at the winning distance (the tournament then reports a miss
-    // at their common ancestor).  Lanes take turns through the exact traversal.
-    unsigned long long pending = __ballot(slow);
-    while (pending != 0ull) {
-        const int turn = __ffsll((long long)pending) - 1;
-        pending &= pending - 1ull;
-        if ((int)(threadIdx.x & 63) == turn) {
-            hit = tournament(ray, tree, leaf, sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1));
-        }
-    }
-    return hit;
-}
-
-// =====================================================================================
 // Kernels
 // =====================================================================================
 
-PT_DEV Mat load_material(const PtMaterial* m) { return Mat{m->v[0], m->v[1], m->v[2], m->v[3], m->type}; }
 
 // Wave -> 8x8 pixel tile, lane -> pixel inside the tile.
 PT_DEV bool pixel_of_thread(const FrameParams& f, int& row, int& column) {
@@ -232,7 +35,7 @@ PT_DEV bool pixel_of_thread(const FrameParams& f, int& row, int& column) {
 // sum is formed in the order the reference's frame loop forms it (src/main.cpp:1001-1036).
 // Lanes regenerate independently: a lane whose path ended starts its next sample while its
 // neighbours are still bouncing.
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(DeviceScene s, FrameParams f, double* __restrict__ accum) {
+__global__ __launch_bounds__(BLOCK_THREADS) void render_pixels_kernel(DeviceScene s, FrameParams f, double* __restrict__ accum) {
     __shared__ BlockShared sh;
     int row, column;
     const bool in_image = pixel_of_thread(f, row, column);
@@ -263,46 +66,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(DeviceScene s, Fr
             const Hit hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, sh);
             // a triangle beyond the sphere hit cannot win (:183), so the search may stop there
             const Hit ht = trace_tree(ray, s.tri_tree, tri_leaf, hs.distance, sh);
-            bool ended;
-            if (hs.index != -1 || ht.index != -1) {
-                D3 p, n;
-                int material_index;
-                if (hs.distance < ht.distance) {                                   // :183-194
-                    const double* sp = s.spheres + 4 * hs.index;
-                    p = add3(ray.o, scale3(hs.distance, ray.d));
-                    const double sign = (sp[3] < 0.0f) ? -1.0f : 1.0f;
-                    n = scale3(sign, unit3(sub3(p, D3{sp[0], sp[1], sp[2]})));
-                    material_index = s.sph_material[hs.index];
-                } else {                                                           // :195-206
-                    const TriRecord* t = s.tris + ht.index;
-                    p = add3(ray.o, scale3(ht.distance, ray.d));
-                    n = D3{t->un[0], t->un[1], t->un[2]};
-                    material_index = s.tri_material[ht.index];
-                }
-                const Mat m = load_material(s.materials + material_index);
-                D3 emission{0.0f, 0.0f, 0.0f};                                     // get_emission, src/material.cpp:64-81
-                if (m.type == PT_DIFFUSE_LIGHT) emission = scale3(m.v3, D3{m.v0, m.v1, m.v2});
-                Ray next;
-                const bool valid = scatter(ray, m, p, n, next);
-                colour = add3(colour, mul3(att, emission));                        // :214 / :217
-                if (valid) {
-                    ray = next;
-                    D3 albedo;                                                     // get_colour, src/material.cpp:39-62
-                    if (m.type == PT_LAMBERTIAN || m.type == PT_METAL) albedo = D3{m.v0, m.v1, m.v2};
-                    else if (m.type == PT_DIELECTRIC) albedo = D3{1.0f, 1.0f, 1.0f};
-                    else albedo = D3{0.0f, 0.0f, 0.0f};
-                    att = mul3(att, albedo);                                       // :215
-                    ++bounce;
-                    ended = (bounce >= f.max_bounces);                             // loop exhaustion, :176
-                } else {
-                    ended = true;                                                  // :218
-                }
-            } else {
-                const double t = 0.5f * (ray.d.y + 1.0f);                          // background_gradient, :99-102
-                const D3 bg = add3(scale3(1.0f - t, s.bg0), scale3(t, s.bg1));
-                colour = add3(colour, mul3(att, bg));                              // :221
-                ended = true;
-            }
+            D3 gain;
+            const bool go_on = shade_vertex(s, ray, hs, ht, att, gain);
+            colour = add3(colour, gain);                                           // :214 / :217 / :221
+            if (go_on) ++bounce;
+            const bool ended = !go_on || bounce >= f.max_bounces;                  // :218, :222, loop exhaustion :176
             if (ended) {
                 sum_b += colour.z;                                                 // src/main.cpp:117-121
                 sum_g += colour.y;
@@ -519,6 +287,13 @@ struct PtScene {
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t last_stream = nullptr;
     bool timed = false;
+    // wavefront kernel: per-path colours, the chunk counter and the profiling counters
+    DeviceBuffer rgb, counters;
+    size_t rgb_bytes = 0;
+    bool albedo_bounded = false;        // every albedo finite with |albedo| <= 1
+    int compute_units = 0, blocks_per_cu = 0;
+    unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool has_stats = false;
     ~PtScene() {
         if (start != nullptr) (void)hipEventDestroy(start);
         if (stop != nullptr) (void)hipEventDestroy(stop);
@@ -573,24 +348,116 @@ FrameParams frame_params(const PtFrame& f) {
     return p;
 }
 
-unsigned grid_blocks(const PtFrame& f) {
+// 8x8 tiles of the frame's rows that belong to the frame's shard.
+long long local_tiles(const PtFrame& f) {
     const long long tiles_x = (f.width + 7) / 8;
     const long long blocks_y = (f.row_end - f.row_begin + 7) / 8;
     const long long shards = f.shard_count > 1 ? f.shard_count : 1;
     const long long index = f.shard_count > 1 ? f.shard_index : 0;
     const long long tiles_y = (blocks_y - index + shards - 1) / shards;   // row blocks index, index+shards, ...
-    const long long waves = tiles_x * tiles_y;
-    return static_cast<unsigned>((waves + (BLOCK_THREADS / 64) - 1) / (BLOCK_THREADS / 64));
+    return tiles_x * tiles_y;
+}
+
+// One wave per tile, four waves per block.
+unsigned grid_blocks(const PtFrame& f) {
+    return static_cast<unsigned>((local_tiles(f) + (BLOCK_THREADS / 64) - 1) / (BLOCK_THREADS / 64));
+}
+
+// Tunables read once from the environment (measurement aids, not part of the interface).
+struct Tunables {
+    bool force_pixels_kernel = false;   // PT_KERNEL=pixels: always the one-lane-per-pixel kernel
+    bool stats = false;                 // PT_STATS=1: count phases and active lanes (slower)
+    double workspace_gb = 16.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer
+    int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
+    Tunables() {
+        if (const char* v = std::getenv("PT_KERNEL")) force_pixels_kernel = std::strcmp(v, "pixels") == 0;
+        if (const char* v = std::getenv("PT_STATS")) stats = std::atoi(v) != 0;
+        if (const char* v = std::getenv("PT_WORKSPACE_GB")) workspace_gb = std::atof(v);
+        if (const char* v = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::atoi(v);
+    }
+};
+const Tunables& tunables() {
+    static const Tunables t;
+    return t;
+}
+
+int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
+    hipLaunchKernelGGL(render_pixels_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream, scene->dev, frame_params(*frame), accum_device);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+template <bool STATS>
+void launch_trace_paths(unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp, const WorkParams& wp,
+                        double* rgb, unsigned int* counter, unsigned long long* stats) {
+    hipLaunchKernelGGL((trace_paths_kernel<STATS, 16, 16>), dim3(blocks), dim3(BLOCK_THREADS), 0, stream, dev, fp, wp, rgb, counter, stats);
+}
+
+// Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
+int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
+    const Tunables& t = tunables();
+    const long long tiles_x = (frame->width + 7) / 8;
+    const long long real_tiles = local_tiles(*frame);
+    const size_t bytes_per_group = static_cast<size_t>(real_tiles) * 3 * CHUNK_PATHS * sizeof(double);
+    const size_t cap = static_cast<size_t>(t.workspace_gb * 1024.0 * 1024.0 * 1024.0);
+    const int total_groups = (frame->sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
+    int groups_per_batch = static_cast<int>(std::max<size_t>(1, cap / bytes_per_group));
+    groups_per_batch = std::min(groups_per_batch, total_groups);
+    const size_t need = bytes_per_group * groups_per_batch;
+    if (scene->rgb_bytes < need) {
+        if (scene->rgb.p != nullptr) { HIP_TRY(hipFree(scene->rgb.p)); scene->rgb.p = nullptr; scene->rgb_bytes = 0; }
+        HIP_TRY(hipMalloc(&scene->rgb.p, need));
+        scene->rgb_bytes = need;
+    }
+    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 128));
+    if (scene->compute_units == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
+        scene->compute_units = prop.multiProcessorCount;
+        int per_cu = 0;
+        if (t.stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_kernel<true, 16, 16>, BLOCK_THREADS, 0));
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_kernel<false, 16, 16>, BLOCK_THREADS, 0));
+        scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
+    }
+    unsigned int* counter = static_cast<unsigned int*>(scene->counters.p);
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(scene->counters.p) + 64);
+    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 128, stream));   // counter of the first batch + profiling counters
+
+    FrameParams fp = frame_params(*frame);
+    const int sample_end = frame->sample_begin + frame->sample_count;
+    bool first = true;
+    for (int begin = frame->sample_begin; begin < sample_end; begin += groups_per_batch * SAMPLES_PER_CHUNK) {
+        fp.sample_begin = begin;
+        fp.sample_count = std::min(groups_per_batch * SAMPLES_PER_CHUNK, sample_end - begin);
+        WorkParams wp;
+        wp.tiles_x = static_cast<int>(tiles_x);
+        wp.groups_per_tile = (fp.sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
+        wp.chunk_count = real_tiles * wp.groups_per_tile;
+        if (wp.chunk_count >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld chunks", wp.chunk_count);
+        if (!first) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
+        first = false;
+        const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
+                                                                          (wp.chunk_count + 3) / 4));
+        if (t.stats) launch_trace_paths<true>(blocks, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats);
+        else launch_trace_paths<false>(blocks, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,
+                           fp, wp, static_cast<const double*>(scene->rgb.p), accum_device);
+        HIP_TRY(hipGetLastError());
+    }
+    scene->has_stats = t.stats;
+    return PT_OK;
 }
 
 int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
     if (frame->row_begin == frame->row_end || frame->sample_count == 0 || grid_blocks(*frame) == 0) return PT_OK;
-    // a path that may not bounce at all contributes nothing but its sample count (the reference's
-    // loop body never runs); the kernel handles that through max_bounces == 0 as well
     HIP_TRY(hipSetDevice(scene->device));
     HIP_TRY(hipEventRecord(scene->start, stream));
-    hipLaunchKernelGGL(render_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream, scene->dev, frame_params(*frame), accum_device);
-    HIP_TRY(hipGetLastError());
+    // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
+    // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
+    const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel;
+    const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream) : launch_pixels_kernel(scene, frame, accum_device, stream);
+    if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->stop, stream));
     scene->last_stream = stream;
     scene->timed = true;
@@ -665,6 +532,13 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
         scene->dev.spheres = scene->spheres.as<double>();
         scene->dev.sph_material = scene->sph_material.as<int32_t>();
     }
+    scene->albedo_bounded = true;
+    for (int i = 0; i < d->material_count; ++i) {
+        const PtMaterial& m = d->materials[i];
+        if (m.type == PT_LAMBERTIAN || m.type == PT_METAL) {
+            for (int c = 0; c < 3; ++c) scene->albedo_bounded = scene->albedo_bounded && std::fabs(m.v[c]) <= 1.0;   // false for NaN too
+        }
+    }
     rc = upload(scene->materials, d->materials, sizeof(PtMaterial) * d->material_count);
     if (rc != PT_OK) return rc;
     scene->dev.materials = scene->materials.as<PtMaterial>();
@@ -735,6 +609,15 @@ int pt_last_render_ms(PtScene* scene, float* ms) {
     HIP_TRY(hipSetDevice(scene->device));
     HIP_TRY(hipEventSynchronize(scene->stop));
     HIP_TRY(hipEventElapsedTime(ms, scene->start, scene->stop));
+    return PT_OK;
+}
+
+int pt_last_render_stats(PtScene* scene, uint64_t* out) {
+    if (scene == nullptr || out == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_last_render_stats: null argument");
+    if (!scene->has_stats) return pt::fail(PT_ERR_UNSUPPORTED, "pt_last_render_stats: the last render did not run the wavefront kernel with PT_STATS=1");
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipEventSynchronize(scene->stop));
+    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->counters.p) + 64, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

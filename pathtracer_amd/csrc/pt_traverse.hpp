@@ -1,0 +1,261 @@
+// HBM scene layout and the per-lane tree searches shared by every kernel.
+#ifndef PT_TRAVERSE_HPP
+#define PT_TRAVERSE_HPP
+
+#include "pt_device.hpp"
+
+namespace ptd {
+
+// PairNode (128 B, one per inner node of the reference tree): both children's boxes and
+// both child references, so one aligned 128-byte fetch decides the two subtrees and lets
+// the nearer one be entered first.  A child reference >= 0 is a PairNode index; < 0 is
+// ~primitive_index of a leaf.  The root node's own box lives in the TreeRef.
+struct PairNode {
+    double lbox[6];
+    double rbox[6];
+    int32_t left, right;
+    int32_t pad_[6];
+};
+static_assert(sizeof(PairNode) == 128, "PairNode is one 128-byte line");
+
+struct TreeRef {
+    const PairNode* pairs;
+    const PtBvhNode* ref_nodes;   // the reference's own node array, for the exhaustive path
+    int32_t root;                 // child-reference encoding; `count == 0` means "no tree"
+    int32_t count;
+    double root_box[6];
+};
+
+struct DeviceScene {
+    TreeRef tri_tree;
+    const TriRecord* tris;
+    const int32_t* tri_material;
+    TreeRef sph_tree;
+    const double* spheres;        // 4 doubles each
+    const int32_t* sph_material;
+    const PtMaterial* materials;
+    D3 bg0, bg1;
+};
+
+struct Hit { int index; double distance; };
+
+struct TriLeaf {
+    const TriRecord* tris;
+    PT_DEV bool test(const Ray& ray, int primitive, double& d) const { return hit_triangle(ray, tris + primitive, d); }
+};
+struct SphLeaf {
+    const double* spheres;
+    PT_DEV bool test(const Ray& ray, int primitive, double& d) const { return hit_sphere(ray, spheres + 4 * primitive, d); }
+};
+
+// Margin added to the best distance before a subtree is skipped: far above any rounding
+// disagreement between a box-entry distance and a primitive distance, far below anything
+// that would cost visits.
+PT_DEV double prune_cut(double limit) { return limit + (1.0e-7 * fabs(limit) + 1.0e-7); }
+
+// The reference's traversal (src/path_tracing.cpp:111-169) evaluated without recursion:
+// every node whose box passes is entered, both children always, and an inner node keeps the
+// strictly smaller child distance; equal distances (two misses included) give a miss.
+// One lane of a wave runs this at a time, with its frames in that wave's LDS slice.
+struct TourFrame { int right; int state; int left_index; double left_distance; };
+
+template <class Leaf>
+__device__ __noinline__ Hit tournament(const Ray& ray, const TreeRef& tree, const Leaf& leaf, TourFrame* frames) {
+    const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+    Hit result{-1, REAL_MAX};
+    int depth = 0;
+    int node = 0;
+    for (;;) {
+        // ---- evaluate `node` downwards until a result exists
+        for (;;) {
+            const PtBvhNode* n = tree.ref_nodes + node;
+            double tmin, tmax;
+            slab_exact(ray.o, inv, &n->aabb.min.x, tmin, tmax);
+            result = Hit{-1, REAL_MAX};
+            if (tmax < 0.0f || tmin > tmax) break;
+            if (n->left == 0 && n->right == 0) {
+                double d;
+                if (leaf.test(ray, n->index, d)) result = Hit{n->index, d};
+                break;
+            }
+            if (depth >= STACK_DEPTH) return Hit{-1, REAL_MAX};   // unreachable: depth is validated at scene creation
+            frames[depth++] = TourFrame{n->right, 0, -1, REAL_MAX};
+            node = n->left;
+        }
+        // ---- hand the result upwards
+        for (;;) {
+            if (depth == 0) return result;
+            TourFrame& f = frames[depth - 1];
+            if (f.state == 0) {
+                f.state = 1;
+                f.left_index = result.index;
+                f.left_distance = result.distance;
+                node = f.right;
+                break;
+            }
+            const Hit l{f.left_index, f.left_distance};
+            if (l.distance < result.distance) result = l;
+            else if (!(result.distance < l.distance)) result = Hit{-1, REAL_MAX};
+            --depth;
+        }
+    }
+}
+
+// Lanes for which the pruned search cannot vouch (`slow`) take turns through the exact traversal.
+template <class Leaf>
+PT_DEV void resolve_slow_lanes(bool slow, const Ray& ray, const TreeRef& tree, const Leaf& leaf, TourFrame* wave_frames, Hit& hit) {
+    unsigned long long pending = __ballot(slow);
+    while (pending != 0ull) {
+        const int turn = __ffsll((long long)pending) - 1;
+        pending &= pending - 1ull;
+        if ((int)(threadIdx.x & 63) == turn) hit = tournament(ray, tree, leaf, wave_frames);
+    }
+}
+
+// Closest-hit search for rays with finite reciprocals: depth-first, nearer child first,
+// subtrees entered beyond `limit` (plus the margin) skipped.  `tie` reports a second leaf at
+// exactly the winning distance; only then can the answer differ from the tournament's.
+template <class Leaf>
+PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Leaf& leaf, double limit, int* stack /* [level*BLOCK_THREADS] */, bool& tie) {
+    Hit best{-1, REAL_MAX};
+    tie = false;
+    double cut = prune_cut(limit);
+    {
+        double tmin, tmax;
+        slab_finite(ray.o, inv, tree.root_box[0], tree.root_box[1], tree.root_box[2], tree.root_box[3], tree.root_box[4], tree.root_box[5], tmin, tmax);
+        if (tmax < 0.0f || tmin > tmax || tmin > cut) return best;
+    }
+    auto visit_leaf = [&](int primitive) {
+        double d;
+        if (leaf.test(ray, primitive, d)) {
+            if (d < best.distance) {
+                best = Hit{primitive, d};
+                tie = false;
+                if (d < limit) {
+                    limit = d;
+                    cut = prune_cut(limit);
+                }
+            } else if (d == best.distance) {
+                tie = true;
+            }
+        }
+    };
+    if (tree.root < 0) {
+        visit_leaf(~tree.root);
+        return best;
+    }
+    int sp = 0;
+    int cur = tree.root;
+    for (;;) {
+        const PairNode* p = tree.pairs + cur;
+        const int lref = p->left, rref = p->right;
+        double lmin, lmax, rmin, rmax;
+        slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
+        slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
+        bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
+        bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+        if (go_l && lref < 0) { visit_leaf(~lref); go_l = false; }
+        if (go_r && rref < 0) { visit_leaf(~rref); go_r = false; }
+        go_l = go_l && !(lmin > cut);
+        go_r = go_r && !(rmin > cut);
+        if (go_l && go_r) {
+            const bool left_first = !(rmin < lmin);
+            stack[sp * BLOCK_THREADS] = left_first ? rref : lref;
+            ++sp;
+            cur = left_first ? lref : rref;
+        } else if (go_l) {
+            cur = lref;
+        } else if (go_r) {
+            cur = rref;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * BLOCK_THREADS];
+        }
+    }
+    return best;
+}
+
+struct BlockShared {
+    int stack[STACK_DEPTH * BLOCK_THREADS];                       // [level][thread]
+    TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];   // one slice per wave
+};
+
+PT_DEV TourFrame* wave_frames(BlockShared& sh) { return sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1); }
+
+// How a ray may be searched.  A NaN anywhere in the ray makes every primitive test fail (the
+// distance is NaN) whatever boxes were entered: the reference walks the tree and reports a
+// miss.  An infinite reciprocal can make slab products NaN, where the exact min/max order
+// of the reference matters: such rays go through the exact traversal.
+enum RayClass { RAY_FINITE = 0, RAY_EXACT_ONLY = 1, RAY_POISONED = 2 };
+PT_DEV int classify_ray(const Ray& ray, D3 inv) {
+    if (any_nan(ray.o) || any_nan(ray.d)) return RAY_POISONED;
+    return (isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z)) ? RAY_FINITE : RAY_EXACT_ONLY;
+}
+
+// Closest hit in one tree with the reference's semantics (whole search by the calling lane).
+template <class Leaf>
+PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, double limit, BlockShared& sh) {
+    Hit hit{-1, REAL_MAX};
+    if (tree.count == 0) return hit;
+    const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+    const int kind = classify_ray(ray, inv);
+    bool slow = (kind == RAY_EXACT_ONLY);
+    if (kind == RAY_FINITE) {
+        bool tie;
+        hit = closest_pruned(ray, inv, tree, leaf, limit, sh.stack + threadIdx.x, tie);
+        slow = tie;
+    }
+    resolve_slow_lanes(slow, ray, tree, leaf, wave_frames(sh), hit);
+    return hit;
+}
+
+PT_DEV Mat load_material(const PtMaterial* m) { return Mat{m->v[0], m->v[1], m->v[2], m->v[3], m->type}; }
+
+// What happens at a hit / miss (src/path_tracing.cpp:179-223).  Returns true if the path
+// goes on with `ray` replaced by the scattered ray; `att` is updated, and `gain` receives the
+// radiance factor picked up at this vertex (emission or background), to be multiplied by the
+// attenuation the path had on arrival.
+PT_DEV bool shade_vertex(const DeviceScene& s, Ray& ray, const Hit& hs, const Hit& ht, D3& att, D3& gain) {
+    if (hs.index != -1 || ht.index != -1) {
+        D3 p, n;
+        int material_index;
+        if (hs.distance < ht.distance) {                                   // :183-194
+            const double* sp = s.spheres + 4 * hs.index;
+            p = add3(ray.o, scale3(hs.distance, ray.d));
+            const double sign = (sp[3] < 0.0f) ? -1.0f : 1.0f;
+            n = scale3(sign, unit3(sub3(p, D3{sp[0], sp[1], sp[2]})));
+            material_index = s.sph_material[hs.index];
+        } else {                                                           // :195-206
+            const TriRecord* t = s.tris + ht.index;
+            p = add3(ray.o, scale3(ht.distance, ray.d));
+            n = D3{t->un[0], t->un[1], t->un[2]};
+            material_index = s.tri_material[ht.index];
+        }
+        const Mat m = load_material(s.materials + material_index);
+        gain = D3{0.0f, 0.0f, 0.0f};                                       // get_emission, src/material.cpp:64-81
+        if (m.type == PT_DIFFUSE_LIGHT) gain = scale3(m.v3, D3{m.v0, m.v1, m.v2});
+        Ray next;
+        const bool valid = scatter(ray, m, p, n, next);
+        if (valid) {
+            ray = next;
+            D3 albedo;                                                     // get_colour, src/material.cpp:39-62
+            if (m.type == PT_LAMBERTIAN || m.type == PT_METAL) albedo = D3{m.v0, m.v1, m.v2};
+            else if (m.type == PT_DIELECTRIC) albedo = D3{1.0f, 1.0f, 1.0f};
+            else albedo = D3{0.0f, 0.0f, 0.0f};
+            gain = mul3(att, gain);                                        // :214, with the arrival attenuation
+            att = mul3(att, albedo);                                       // :215
+            return true;
+        }
+        gain = mul3(att, gain);                                            // :217
+        return false;
+    }
+    const double t = 0.5f * (ray.d.y + 1.0f);                              // background_gradient, :99-102
+    const D3 bg = add3(scale3(1.0f - t, s.bg0), scale3(t, s.bg1));
+    gain = mul3(att, bg);                                                  // :221
+    return false;
+}
+
+}  // namespace ptd
+
+#endif

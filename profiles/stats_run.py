@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Runs the wavefront kernel with PT_STATS=1 on a reduced-spp frame and prints phase/lane counts.
+usage: PT_STATS=1 python profiles/stats_run.py [spp] [scene]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pathtracer_amd import api, ctypes_abi as abi
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+kind = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED}[sys.argv[2] if len(sys.argv) > 2 else "chess32"]
+host = api.HostScene(kind, api.MODELS_DIR)
+dev = api.DeviceScene.from_host(host)
+w, h = 1920, 1080
+buf = torch.zeros(4 * w * h, dtype=torch.float64, device="cuda:0")
+fr = host.frame(w, h, sample_count=spp)
+for i in range(2):
+    buf.zero_()
+    dev.render_device(fr, buf.data_ptr())
+    torch.cuda.synchronize()
+ms = dev.last_render_ms()
+out = {"spp": spp, "ms": ms, "msamples_per_s": w * h * spp / ms / 1e3}
+try:
+    st = dev.last_render_stats()
+    out["stats"] = st
+    for k in ("node", "leaf", "shade"):
+        out[k + "_lanes_per_phase"] = st[k + "_lanes"] / max(1, st[k + "_phases"])
+    out["per_path"] = {k: st[k + "_lanes"] / st["paths"] for k in ("node", "leaf", "shade")}
+except Exception as e:
+    out["stats_error"] = str(e)
+print(json.dumps(out))
