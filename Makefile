@@ -13,16 +13,16 @@ LIB      := pathtracer_amd/libpathtracer_amd.so
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wextra -Wno-unused-parameter
 HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter $(EXTRA_HIPFLAGS)
 
-HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp
+HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp $(CSRC)/sah_build.cpp
 HOST_OBJS := $(HOST_SRCS:.cpp=.o)
 HIP_OBJS  := $(CSRC)/pt_gpu.o
 
 all: $(LIB) oracle
 
-$(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/pt_internal.h include/pathtracer_amd.h
+$(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/pt_internal.h $(CSRC)/pt_traverse_host.h include/pathtracer_amd.h
 	$(CXX) $(HOSTFLAGS) -c -o $@ $<
 
-$(CSRC)/pt_gpu.o: $(CSRC)/pt_gpu.hip $(CSRC)/pt_device.hpp $(CSRC)/pt_internal.h include/pathtracer_amd.h
+$(CSRC)/pt_gpu.o: $(CSRC)/pt_gpu.hip $(CSRC)/pt_device.hpp $(CSRC)/pt_traverse.hpp $(CSRC)/pt_wavefront.hpp $(CSRC)/pt_traverse_host.h $(CSRC)/pt_internal.h include/pathtracer_amd.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(HOST_OBJS) $(HIP_OBJS)

@@ -209,8 +209,10 @@ int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_inde
 int pt_last_render_ms(PtScene* scene, float* ms);
 
 /* Profiling aid, not in the reference: with PT_STATS=1 in the environment the wavefront kernel
- * counts its phases; out[0..7] = node phases, lanes active in them, leaf phases, lanes, shade
- * phases, lanes, loop iterations, paths started (all summed over waves). */
+ * counts its phases; `out` holds 16 values: node phases, lanes active in them, leaf phases,
+ * lanes, shade phases, lanes, loop iterations, paths started, and the number of boxes the
+ * single-precision test skipped although the exact test accepts them (must be 0); the rest
+ * are reserved.  All summed over waves. */
 int pt_last_render_stats(PtScene* scene, uint64_t* out);
 
 /* Device self-test hook: evaluates one device-side building block of the path

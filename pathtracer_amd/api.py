@@ -231,9 +231,10 @@ class DeviceScene:
         return ms.value
 
     def last_render_stats(self):
-        out = np.zeros(8, np.uint64)
+        out = np.zeros(16, np.uint64)
         check(lib().pt_last_render_stats(self.handle, ptr(out)))
-        names = ["node_phases", "node_lanes", "leaf_phases", "leaf_lanes", "shade_phases", "shade_lanes", "loops", "paths"]
+        names = ["node_phases", "node_lanes", "leaf_phases", "leaf_lanes", "shade_phases", "shade_lanes", "loops", "paths",
+                 "unsafe_skips"]
         return dict(zip(names, out.tolist()))
 
     def primary_hits(self, frame):

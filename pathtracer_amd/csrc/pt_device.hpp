@@ -118,7 +118,9 @@ struct TriRecord {
 };
 static_assert(sizeof(TriRecord) == 128, "TriRecord is one 128-byte line");
 
-PT_DEV bool hit_triangle(const Ray& ray, const TriRecord* __restrict__ t, double& distance) {
+// `Record` is any struct with the fields a, ab, ac, n (double[3]) and nn.
+template <class Record>
+PT_DEV bool hit_triangle(const Ray& ray, const Record* __restrict__ t, double& distance) {
     const D3 a{t->a[0], t->a[1], t->a[2]};
     const D3 ab{t->ab[0], t->ab[1], t->ab[2]};
     const D3 ac{t->ac[0], t->ac[1], t->ac[2]};

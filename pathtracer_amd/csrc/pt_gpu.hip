@@ -12,6 +12,7 @@
 
 #include "pt_wavefront.hpp"
 #include "pt_internal.h"
+#include "pt_traverse_host.h"
 
 using namespace ptd;
 
@@ -282,7 +283,8 @@ D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
 struct PtScene {
     int device = 0;
     DeviceScene dev{};
-    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material;
+    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material, tri_pairs32, tri_leaves;
+    int tri_height = 0, sph_height = 0;
     DeviceBuffer sph_pairs, sph_ref_nodes, spheres, sph_material, materials;
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t last_stream = nullptr;
@@ -303,14 +305,37 @@ struct PtScene {
 namespace {
 
 int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, DeviceBuffer& pairs_buffer,
-               DeviceBuffer& ref_buffer, TreeRef* tree) {
+               DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, std::vector<PairNode>* pairs_out, bool rebuild) {
     int height = 0;
     int rc = validate_tree(nodes, node_count, primitive_count, what, &height);
     if (rc != PT_OK) return rc;
     if (height > STACK_DEPTH) return pt::fail(PT_ERR_UNSUPPORTED, "%s BVH is %d levels deep; the traversal stack holds %d", what, height, STACK_DEPTH);
-    std::vector<PairNode> pairs;
+    std::vector<PairNode> local_pairs;
+    std::vector<PairNode>& pairs = pairs_out != nullptr ? *pairs_out : local_pairs;
     int32_t root = 0;
-    flatten_tree(nodes, node_count, &pairs, &root);
+    bool rebuilt = false;
+    if (rebuild && primitive_count > 2) {
+        // The search hierarchy is this library's own (see sah_build.cpp); the reference's tree is
+        // kept beside it for the exact traversal.  Leaf boxes are taken from the reference's leaves.
+        std::vector<PtAabb> boxes(primitive_count);
+        for (int i = 0; i < node_count; ++i) {
+            if (nodes[i].left == 0 && nodes[i].right == 0) boxes[nodes[i].index] = nodes[i].aabb;
+        }
+        std::vector<PairNodeHost> host_pairs;
+        int sah_root = 0, sah_height = 0;
+        static_assert(sizeof(PairNodeHost) == sizeof(PairNode), "host and device pair nodes must match");
+        if (pt::build_sah_pairs(boxes, WF_STACK_DEPTH + 1, &host_pairs, &sah_root, &sah_height) == PT_OK) {
+            pairs.resize(host_pairs.size());
+            std::memcpy(pairs.data(), host_pairs.data(), host_pairs.size() * sizeof(PairNode));
+            root = sah_root;
+            height = sah_height;
+            rebuilt = true;
+        } else {
+            pt::clear_error();
+        }
+    }
+    if (!rebuilt) flatten_tree(nodes, node_count, &pairs, &root);
+    *height_out = height;
     rc = upload(pairs_buffer, pairs.data(), pairs.size() * sizeof(PairNode));
     if (rc != PT_OK) return rc;
     rc = upload(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
@@ -320,6 +345,57 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
     tree->root = root;
     tree->count = primitive_count;
     std::memcpy(tree->root_box, &nodes[0].aabb, 48);
+    return PT_OK;
+}
+
+float outward_down(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) > x) ? std::nextafterf(f, -INFINITY) : f; }
+float outward_up(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) < x) ? std::nextafterf(f, INFINITY) : f; }
+
+// Single-precision inner nodes (boxes rounded outward) and the leaf records of the wavefront
+// kernel.  Skipped, leaving tri_pairs32 null, when a coordinate is outside the range in which
+// the f32 slab products are guaranteed finite.
+int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, PtScene* scene) {
+    const PtAabb& root = d.triangle_bvh[0].aabb;
+    const double extent[6] = {root.min.x, root.min.y, root.min.z, root.max.x, root.max.y, root.max.z};
+    for (double v : extent) {
+        if (!(std::fabs(v) <= MAX_COORD32)) return PT_OK;      // also false for NaN
+    }
+    std::vector<PairNode32> pairs32(pairs.size());
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        for (int k = 0; k < 3; ++k) {
+            pairs32[i].lbox[k] = outward_down(pairs[i].lbox[k]);
+            pairs32[i].lbox[3 + k] = outward_up(pairs[i].lbox[3 + k]);
+            pairs32[i].rbox[k] = outward_down(pairs[i].rbox[k]);
+            pairs32[i].rbox[3 + k] = outward_up(pairs[i].rbox[3 + k]);
+        }
+        pairs32[i].left = pairs[i].left;
+        pairs32[i].right = pairs[i].right;
+        pairs32[i].pad_[0] = pairs32[i].pad_[1] = 0;
+    }
+    std::vector<LeafRecord> leaves(d.triangle_count);
+    for (int i = 0; i < d.triangle_count; ++i) {
+        using namespace pt;
+        const PtTriangle& t = d.triangles[i];
+        const PtAabb box = box_of(t);                      // the leaf's box exactly as the reference's BVH stores it
+        const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
+        const PtVec3 n = cross(ab, ac);
+        LeafRecord& r = leaves[i];
+        r.box[0] = box.min.x; r.box[1] = box.min.y; r.box[2] = box.min.z;
+        r.box[3] = box.max.x; r.box[4] = box.max.y; r.box[5] = box.max.z;
+        r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
+        r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
+        r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
+        r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
+        r.nn = dot(n, n);
+        r.pad_ = 0.0;
+    }
+    int rc = upload(scene->tri_pairs32, pairs32.data(), pairs32.size() * sizeof(PairNode32));
+    if (rc != PT_OK) return rc;
+    rc = upload(scene->tri_leaves, leaves.data(), leaves.size() * sizeof(LeafRecord));
+    if (rc != PT_OK) return rc;
+    scene->dev.tri_pairs32 = pairs32.empty() && d.triangle_count != 1 ? nullptr : scene->tri_pairs32.as<PairNode32>();
+    scene->dev.tri_leaves = scene->tri_leaves.as<LeafRecord>();
+    if (d.triangle_count == 1) scene->dev.tri_pairs32 = reinterpret_cast<const PairNode32*>(scene->dev.tri_leaves);   // no inner node exists; any non-null value enables the path
     return PT_OK;
 }
 
@@ -369,7 +445,15 @@ struct Tunables {
     bool stats = false;                 // PT_STATS=1: count phases and active lanes (slower)
     double workspace_gb = 16.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
+    bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
+    bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
+    int shade_threshold = 16;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
+    int leaf_threshold = 16;
     Tunables() {
+        if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
+        if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
+        if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
+        if (const char* v = std::getenv("PT_LEAF_THRESHOLD")) leaf_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_KERNEL")) force_pixels_kernel = std::strcmp(v, "pixels") == 0;
         if (const char* v = std::getenv("PT_STATS")) stats = std::atoi(v) != 0;
         if (const char* v = std::getenv("PT_WORKSPACE_GB")) workspace_gb = std::atof(v);
@@ -387,10 +471,28 @@ int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_dev
     return PT_OK;
 }
 
-template <bool STATS>
-void launch_trace_paths(unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp, const WorkParams& wp,
-                        double* rgb, unsigned int* counter, unsigned long long* stats) {
-    hipLaunchKernelGGL((trace_paths_kernel<STATS, 16, 16>), dim3(blocks), dim3(BLOCK_THREADS), 0, stream, dev, fp, wp, rgb, counter, stats);
+template <bool STATS, bool NODE32>
+int launch_trace_paths(unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp, const WorkParams& wp,
+                       double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
+    auto kernel = trace_paths_kernel<STATS, NODE32>;
+    if (blocks_per_cu != nullptr) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, BLOCK_THREADS, 0));
+        return PT_OK;
+    }
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, dev, fp, wp, rgb, counter, stats);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+// Dispatch over the two compile-time switches; with `blocks_per_cu` set it only queries occupancy.
+int trace_paths(bool stats_build, bool node32, unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
+                const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
+    if (stats_build) {
+        return node32 ? launch_trace_paths<true, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                      : launch_trace_paths<true, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    }
+    return node32 ? launch_trace_paths<false, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                  : launch_trace_paths<false, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
 }
 
 // Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
@@ -409,19 +511,20 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         HIP_TRY(hipMalloc(&scene->rgb.p, need));
         scene->rgb_bytes = need;
     }
-    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 128));
+    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 256));
+    const bool node32 = scene->dev.tri_pairs32 != nullptr && !t.force_f64_nodes;
     if (scene->compute_units == 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
         scene->compute_units = prop.multiProcessorCount;
         int per_cu = 0;
-        if (t.stats) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_kernel<true, 16, 16>, BLOCK_THREADS, 0));
-        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_kernel<false, 16, 16>, BLOCK_THREADS, 0));
+        const int rc = trace_paths(t.stats, node32, 0, stream, scene->dev, FrameParams{}, WorkParams{}, nullptr, nullptr, nullptr, &per_cu);
+        if (rc != PT_OK) return rc;
         scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
     }
     unsigned int* counter = static_cast<unsigned int*>(scene->counters.p);
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(scene->counters.p) + 64);
-    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 128, stream));   // counter of the first batch + profiling counters
+    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 256, stream));   // counter of the first batch + profiling counters
 
     FrameParams fp = frame_params(*frame);
     const int sample_end = frame->sample_begin + frame->sample_count;
@@ -433,14 +536,15 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.tiles_x = static_cast<int>(tiles_x);
         wp.groups_per_tile = (fp.sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
         wp.chunk_count = real_tiles * wp.groups_per_tile;
+        wp.shade_threshold = t.shade_threshold;
+        wp.leaf_threshold = t.leaf_threshold;
         if (wp.chunk_count >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld chunks", wp.chunk_count);
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
         first = false;
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
                                                                           (wp.chunk_count + 3) / 4));
-        if (t.stats) launch_trace_paths<true>(blocks, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats);
-        else launch_trace_paths<false>(blocks, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats);
-        HIP_TRY(hipGetLastError());
+        const int rc = trace_paths(t.stats, node32, blocks, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats, nullptr);
+        if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,
                            fp, wp, static_cast<const double*>(scene->rgb.p), accum_device);
         HIP_TRY(hipGetLastError());
@@ -455,7 +559,8 @@ int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hi
     HIP_TRY(hipEventRecord(scene->start, stream));
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
-    const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel;
+    const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel &&
+                           scene->tri_height <= WF_STACK_DEPTH + 1 && scene->sph_height <= WF_STACK_DEPTH + 1;
     const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream) : launch_pixels_kernel(scene, frame, accum_device, stream);
     if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->stop, stream));
@@ -496,7 +601,11 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
     scene->device = device;
     int rc;
     if (d->triangle_count > 0) {
-        rc = build_tree(d->triangle_bvh, d->triangle_bvh_node_count, d->triangle_count, "triangle", scene->tri_pairs, scene->tri_ref_nodes, &scene->dev.tri_tree);
+        std::vector<PairNode> pairs;
+        rc = build_tree(d->triangle_bvh, d->triangle_bvh_node_count, d->triangle_count, "triangle", scene->tri_pairs, scene->tri_ref_nodes,
+                        &scene->dev.tri_tree, &scene->tri_height, &pairs, !tunables().reference_topology);
+        if (rc != PT_OK) return rc;
+        rc = build_f32_nodes(*d, pairs, scene.get());
         if (rc != PT_OK) return rc;
         // ray-independent part of the triangle test, same operations as src/geometry.cpp:111-114, :124, :84-90
         std::vector<TriRecord> records(d->triangle_count);
@@ -523,7 +632,8 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
         scene->dev.tri_material = scene->tri_material.as<int32_t>();
     }
     if (d->sphere_count > 0) {
-        rc = build_tree(d->sphere_bvh, d->sphere_bvh_node_count, d->sphere_count, "sphere", scene->sph_pairs, scene->sph_ref_nodes, &scene->dev.sph_tree);
+        rc = build_tree(d->sphere_bvh, d->sphere_bvh_node_count, d->sphere_count, "sphere", scene->sph_pairs, scene->sph_ref_nodes,
+                        &scene->dev.sph_tree, &scene->sph_height, nullptr, false);
         if (rc != PT_OK) return rc;
         rc = upload(scene->spheres, d->spheres, sizeof(PtSphere) * d->sphere_count);
         if (rc != PT_OK) return rc;
@@ -617,7 +727,7 @@ int pt_last_render_stats(PtScene* scene, uint64_t* out) {
     if (!scene->has_stats) return pt::fail(PT_ERR_UNSUPPORTED, "pt_last_render_stats: the last render did not run the wavefront kernel with PT_STATS=1");
     HIP_TRY(hipSetDevice(scene->device));
     HIP_TRY(hipEventSynchronize(scene->stop));
-    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->counters.p) + 64, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->counters.p) + 64, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

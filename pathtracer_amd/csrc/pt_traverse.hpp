@@ -26,10 +26,93 @@ struct TreeRef {
     double root_box[6];
 };
 
+// ---------------------------------------------------------------------------------------------
+// Single-precision inner nodes (64 B per pair) for the wavefront kernel.
+//
+// For a ray whose reciprocals are finite, a box that lies inside another box passes the
+// reference's slab test only if the outer box passes it too, and its entry distance is no
+// smaller (rounded subtraction and rounded multiplication by a fixed factor are monotone).
+// So which leaves the reference reaches depends only on each leaf's OWN box, and inner boxes
+// serve purely to skip subtrees.  They may therefore be tested conservatively in f32, as long
+// as no subtree is skipped that holds a leaf the exact test would accept within the pruning
+// distance; the exact f64 box test is then repeated at the leaf (LeafRecord::box).
+//
+// Conservative test: boxes are stored rounded outward; the lower plane is taken relative to
+// the origin rounded up and the upper plane relative to the origin rounded down, so before
+// rounding the f32 slab interval contains the exact one; the three roundings per product
+// (subtract, reciprocal, multiply: 3 * 2^-24 relative) are covered by widening the interval by
+// RHO = 2^-20 relative plus EPS32 absolute (denormal range).
+struct PairNode32 {
+    float lbox[6];
+    float rbox[6];
+    int32_t left, right;
+    int32_t pad_[2];
+};
+static_assert(sizeof(PairNode32) == 64, "PairNode32 is half a 128-byte line");
+
+// Everything a leaf visit needs: the leaf's exact box, then the ray-independent part of the
+// triangle test (same fields as TriRecord without the unit normal).  160 B = ten 16-byte loads.
+struct LeafRecord {
+    double box[6];
+    double a[3], ab[3], ac[3], n[3], nn;
+    double pad_;
+};
+static_assert(sizeof(LeafRecord) == 160, "LeafRecord is ten 16-byte pieces");
+
+constexpr float RHO32 = 9.5367431640625e-07f;    // 2^-20
+constexpr float EPS32 = 1.0e-30f;
+constexpr double MAX_COORD32 = 1048576.0;        // |coordinate| <= 2^20 keeps every f32 product finite
+constexpr double MAX_INV32 = 1.2676506002282294e30;   // 2^100
+
+struct Ray32 {
+    float ohx, ohy, ohz;     // origin rounded up
+    float olx, oly, olz;     // origin rounded down
+    float ix, iy, iz;        // reciprocals, rounded to nearest
+};
+
+PT_DEV float next_up32(float f) {      // smallest float > f (finite f)
+    const uint32_t u = __float_as_uint(f);
+    if (f == 0.0f) return __uint_as_float(1u);
+    return __uint_as_float((u >> 31) ? u - 1u : u + 1u);
+}
+PT_DEV float next_down32(float f) { return -next_up32(-f); }
+PT_DEV float round_up32(double x) { const float f = (float)x; return ((double)f < x) ? next_up32(f) : f; }
+PT_DEV float round_down32(double x) { const float f = (float)x; return ((double)f > x) ? next_down32(f) : f; }
+
+// True if the ray may use the f32 inner nodes (otherwise it takes the exact traversal).
+PT_DEV bool ray32_allowed(const Ray& ray, D3 inv) {
+    return fabs(inv.x) <= MAX_INV32 && fabs(inv.y) <= MAX_INV32 && fabs(inv.z) <= MAX_INV32 &&
+           fabs(ray.o.x) <= MAX_COORD32 && fabs(ray.o.y) <= MAX_COORD32 && fabs(ray.o.z) <= MAX_COORD32;
+}
+PT_DEV Ray32 make_ray32(const Ray& ray, D3 inv) {
+    return Ray32{round_up32(ray.o.x), round_up32(ray.o.y), round_up32(ray.o.z),
+                 round_down32(ray.o.x), round_down32(ray.o.y), round_down32(ray.o.z),
+                 (float)inv.x, (float)inv.y, (float)inv.z};
+}
+// Upper bound, as a float, of the pruning distance.
+PT_DEV float cut32_of(double cut) { return (float)((cut + 1.0e-30) * (1.0 + 4.76837158203125e-07)); }
+
+// Conservative bounds of one box: `lower` <= exact entry distance, `upper` >= exact exit distance.
+PT_DEV void slab32(const Ray32& r, float b0, float b1, float b2, float b3, float b4, float b5, float& lower, float& upper) {
+    const float x0 = (b0 - r.ohx) * r.ix, x1 = (b3 - r.olx) * r.ix;
+    const float y0 = (b1 - r.ohy) * r.iy, y1 = (b4 - r.oly) * r.iy;
+    const float z0 = (b2 - r.ohz) * r.iz, z1 = (b5 - r.olz) * r.iz;
+    const float tmin = fmaxf(fminf(z0, z1), fmaxf(fminf(y0, y1), fminf(x0, x1)));
+    const float tmax = fminf(fmaxf(z0, z1), fminf(fmaxf(y0, y1), fmaxf(x0, x1)));
+    lower = fmaf(fabsf(tmin), -RHO32, tmin);
+    upper = fmaf(fabsf(tmax), RHO32, tmax);
+}
+// May the subtree be skipped?  Never true for a box the exact test accepts within `cut`.
+PT_DEV bool skip32(float lower, float upper, float cut32) {
+    return (upper < -EPS32) || (lower - upper > EPS32) || (lower > cut32);
+}
+
 struct DeviceScene {
     TreeRef tri_tree;
     const TriRecord* tris;
     const int32_t* tri_material;
+    const PairNode32* tri_pairs32;   // same numbering as tri_tree.pairs; null if the scene is out of f32 range
+    const LeafRecord* tri_leaves;
     TreeRef sph_tree;
     const double* spheres;        // 4 doubles each
     const int32_t* sph_material;
@@ -194,8 +277,10 @@ PT_DEV int classify_ray(const Ray& ray, D3 inv) {
 }
 
 // Closest hit in one tree with the reference's semantics (whole search by the calling lane).
+// `lane_stack` is the calling lane's column of an LDS stack laid out [level][BLOCK_THREADS];
+// `frames` is the calling wave's slice of tournament frames.
 template <class Leaf>
-PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, double limit, BlockShared& sh) {
+PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, double limit, int* lane_stack, TourFrame* frames) {
     Hit hit{-1, REAL_MAX};
     if (tree.count == 0) return hit;
     const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
@@ -203,11 +288,15 @@ PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, dou
     bool slow = (kind == RAY_EXACT_ONLY);
     if (kind == RAY_FINITE) {
         bool tie;
-        hit = closest_pruned(ray, inv, tree, leaf, limit, sh.stack + threadIdx.x, tie);
+        hit = closest_pruned(ray, inv, tree, leaf, limit, lane_stack, tie);
         slow = tie;
     }
-    resolve_slow_lanes(slow, ray, tree, leaf, wave_frames(sh), hit);
+    resolve_slow_lanes(slow, ray, tree, leaf, frames, hit);
     return hit;
+}
+template <class Leaf>
+PT_DEV Hit trace_tree(const Ray& ray, const TreeRef& tree, const Leaf& leaf, double limit, BlockShared& sh) {
+    return trace_tree(ray, tree, leaf, limit, sh.stack + threadIdx.x, wave_frames(sh));
 }
 
 PT_DEV Mat load_material(const PtMaterial* m) { return Mat{m->v[0], m->v[1], m->v[2], m->v[3], m->type}; }

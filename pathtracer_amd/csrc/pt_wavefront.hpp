@@ -11,7 +11,7 @@
 //                        samples) from a counter in HBM and write each path's colour to
 //                        `rgb`; a lane that finishes a path takes the next one, so all 64
 //                        lanes stay busy until the frame runs out of work.  Inside the wave,
-//                        lanes are regrouped with ballots: node steps, triangle tests and
+//                        lanes are regrouped with ballots: node steps, leaf tests and
 //                        shading each run when enough lanes want them, never one lane at a time.
 //   sum_samples_kernel   one lane per pixel adds that pixel's colours in ascending sample
 //                        order into the accumulation buffer: the reference's order, bit for bit.
@@ -28,11 +28,14 @@ namespace ptd {
 
 constexpr int SAMPLES_PER_CHUNK = 16;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
+constexpr int WF_STACK_DEPTH = 24;     // trees up to 25 levels (2^24 leaves in the reference's balanced build)
 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
     int groups_per_tile;         // ceil(sample_count / SAMPLES_PER_CHUNK)
     long long chunk_count;       // tiles_x * local row blocks * groups_per_tile
+    int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
+    int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
 };
 
 // rgb layout: [chunk][channel r,g,b][CHUNK_PATHS] doubles; path j of a chunk is sample
@@ -43,24 +46,36 @@ enum LaneState { ST_NEED = 0, ST_NODE = 1, ST_LEAF = 2, ST_SHADE = 3, ST_NEWRAY 
 
 struct WaveStats {   // wave-uniform counters of a profiling build
     unsigned long long node_phases, node_lanes, leaf_phases, leaf_lanes, shade_phases, shade_lanes, loops, paths;
+    unsigned long long unsafe_skips;   // f32 test skipped a box the exact test accepts: must stay 0
 };
 
-template <bool STATS, int S_THRESHOLD, int L_THRESHOLD>
+struct WaveShared {
+    int stack_ref[WF_STACK_DEPTH * BLOCK_THREADS];      // [level][thread]: pending far children
+    float stack_low[WF_STACK_DEPTH * BLOCK_THREADS];    // lower bound of their entry distance
+    TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];
+};
+
+// NODE32: inner nodes are the 64-byte single-precision pairs (conservative test, exact test
+// repeated at the leaf); otherwise the 128-byte double-precision pairs, whose test is the
+// reference's own.
+template <bool STATS, bool NODE32>
 __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene s, FrameParams f, WorkParams w,
                                                                     double* __restrict__ rgb,
                                                                     unsigned int* __restrict__ next_chunk,
                                                                     unsigned long long* __restrict__ stats) {
-    __shared__ BlockShared sh;
+    __shared__ WaveShared sh;
     const int lane = threadIdx.x & 63;
-    int* const stack = sh.stack + threadIdx.x;
+    int* const stack_ref = sh.stack_ref + threadIdx.x;
+    float* const stack_low = sh.stack_low + threadIdx.x;
+    TourFrame* const frames = sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1);
     const TriLeaf tri_leaf{s.tris};
     const SphLeaf sph_leaf{s.spheres};
 
-    // wave-uniform work state
-    long long chunk = -1;
-    int chunk_next = 0, chunk_size = 0;
+    // wave-uniform work state: the chunk being handed out and where its tile and samples lie
+    unsigned int chunk = 0;
+    int chunk_next = 0, chunk_size = 0, chunk_row0 = 0, chunk_col0 = 0, chunk_sample0 = 0;
     bool work_left = true;
-    WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0};
+    WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // per-lane path state
     int st = ST_NEED;
@@ -68,9 +83,23 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
     long long slot = 0;                 // chunk * CHUNK_PATHS + j of the lane's path
     bool tie = false;
     double best_t = REAL_MAX, cut = REAL_MAX;
+    float cut32 = 0.0f;
     Hit hs{-1, REAL_MAX};
     Ray ray{D3{0, 0, 0}, D3{0, 0, 1}};
     D3 inv{0, 0, 1}, att{1.0f, 1.0f, 1.0f};
+    Ray32 r32{0, 0, 0, 0, 0, 0, 1, 1, 1};
+
+    // Leaves the current node: next pending subtree that can still matter, or the end of the search.
+    auto pop = [&]() {
+        for (;;) {
+            if (sp == 0) { st = ST_SHADE; return; }
+            --sp;
+            cur = stack_ref[sp * BLOCK_THREADS];
+            if (NODE32 && stack_low[sp * BLOCK_THREADS] > cut32) continue;   // fell behind the best hit since it was pushed
+            st = (cur < 0) ? ST_LEAF : ST_NODE;
+            return;
+        }
+    };
 
     for (;;) {
         const unsigned long long m_node = __ballot(st == ST_NODE);
@@ -79,13 +108,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
         const int n_ready = __popcll(m_ready);
         if (STATS) ++ws.loops;
 
-        if ((m_node | m_leaf) == 0ull || n_ready >= S_THRESHOLD) {
+        if ((m_node | m_leaf) == 0ull || n_ready >= w.shade_threshold) {
             if (n_ready == 0) break;      // nothing in flight, nothing to shade, no work left
             if (STATS) { ++ws.shade_phases; ws.shade_lanes += n_ready; }
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
-                resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, wave_frames(sh), ht);
+                resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
                 D3 gain;
                 const bool go_on = shade_vertex(s, ray, hs, ht, att, gain);
                 ++bounce;
@@ -110,26 +139,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                     if (lane == 0) c = atomicAdd(next_chunk, 1u);
                     c = __builtin_amdgcn_readfirstlane(c);
                     if ((long long)c >= w.chunk_count) { work_left = false; break; }
-                    chunk = (long long)c;
+                    chunk = c;
                     chunk_next = 0;
-                    const int group = (int)(chunk % w.groups_per_tile);
-                    const int samples = min(SAMPLES_PER_CHUNK, f.sample_count - group * SAMPLES_PER_CHUNK);
-                    chunk_size = 64 * samples;
+                    const unsigned int tile = c / (unsigned int)w.groups_per_tile;
+                    const int group = (int)(c - tile * (unsigned int)w.groups_per_tile);
+                    const unsigned int tile_row = tile / (unsigned int)w.tiles_x;
+                    chunk_col0 = (int)(tile - tile_row * (unsigned int)w.tiles_x) * 8;
+                    chunk_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
+                    chunk_sample0 = f.sample_begin + group * SAMPLES_PER_CHUNK;
+                    chunk_size = 64 * min(SAMPLES_PER_CHUNK, f.sample_count - group * SAMPLES_PER_CHUNK);
                 }
                 const int rank = __popcll(m_need & ((1ull << lane) - 1ull));
                 const int available = chunk_size - chunk_next;
                 if (st == ST_NEED && rank < available) {
                     const int j = chunk_next + rank;
-                    const long long tile = chunk / w.groups_per_tile;
-                    const int group = (int)(chunk % w.groups_per_tile);
-                    const int tile_row = (int)(tile / w.tiles_x) * f.shard_count + f.shard_index;
-                    const int tile_col = (int)(tile % w.tiles_x);
                     const int pixel = j & 63;
-                    const int row = f.row_begin + tile_row * 8 + (pixel >> 3);
-                    const int column = tile_col * 8 + (pixel & 7);
-                    const int sample = f.sample_begin + group * SAMPLES_PER_CHUNK + (j >> 6);
+                    const int row = chunk_row0 + (pixel >> 3);
+                    const int column = chunk_col0 + (pixel & 7);
+                    const int sample = chunk_sample0 + (j >> 6);
                     if (row < f.row_end && column < f.width) {
-                        slot = chunk * CHUNK_PATHS + j;
+                        slot = (long long)chunk * CHUNK_PATHS + j;
                         ray = camera_ray(f, row, column, sample);
                         att = D3{1.0f, 1.0f, 1.0f};
                         bounce = 0;
@@ -144,17 +173,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
             // ---------------- start the search of every new ray (src/path_tracing.cpp:177-178)
             if (st == ST_NEWRAY) {
                 inv = D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
-                hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, sh);
+                if (s.sph_tree.count == 1) {
+                    // one sphere: its node is the root and a leaf; the reference tests the box, then the sphere
+                    // (src/path_tracing.cpp:113-127); min/max order matters only if a slab product is NaN
+                    hs = Hit{-1, REAL_MAX};
+                    double tmin, tmax, d;
+                    slab_exact(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
+                    if (!(tmax < 0.0f || tmin > tmax) && hit_sphere(ray, s.spheres, d)) hs = Hit{0, d};
+                } else {
+                    hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, stack_ref, frames);
+                }
                 best_i = -1;
                 best_t = REAL_MAX;
                 tie = false;
                 sp = 0;
                 st = ST_SHADE;                       // unless a search is started below
                 if (s.tri_tree.count > 0) {
-                    const int kind = classify_ray(ray, inv);
+                    int kind = classify_ray(ray, inv);
+                    if (NODE32 && kind == RAY_FINITE && !ray32_allowed(ray, inv)) kind = RAY_EXACT_ONLY;
                     if (kind == RAY_EXACT_ONLY) {
                         Hit ht{-1, REAL_MAX};
-                        resolve_slow_lanes(true, ray, s.tri_tree, tri_leaf, wave_frames(sh), ht);
+                        resolve_slow_lanes(true, ray, s.tri_tree, tri_leaf, frames, ht);
                         best_i = ht.index;
                         best_t = ht.distance;
                     } else if (kind == RAY_FINITE) {
@@ -166,61 +205,98 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                         if (!(tmax < 0.0f || tmin > tmax || tmin > cut)) {
                             cur = s.tri_tree.root;
                             st = (cur < 0) ? ST_LEAF : ST_NODE;
+                            if (NODE32) {
+                                r32 = make_ray32(ray, inv);
+                                cut32 = cut32_of(cut);
+                            }
                         }
                     }
                 }
             }
-        } else if (m_node == 0ull || __popcll(m_leaf) >= L_THRESHOLD) {
-            // ---------------- triangle tests for the lanes standing on a leaf
+        } else if (m_node == 0ull || __popcll(m_leaf) >= w.leaf_threshold) {
+            // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
             if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(m_leaf); }
             if (st == ST_LEAF) {
                 const int primitive = ~cur;
+                bool enter = true;
                 double d;
-                if (hit_triangle(ray, s.tris + primitive, d)) {
+                bool hit;
+                if (NODE32) {
+                    const LeafRecord* leaf = s.tri_leaves + primitive;
+                    double tmin, tmax;
+                    slab_finite(ray.o, inv, leaf->box[0], leaf->box[1], leaf->box[2], leaf->box[3], leaf->box[4], leaf->box[5], tmin, tmax);
+                    enter = !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
+                    hit = false;
+                    if (enter) {
+                        hit = hit_triangle(ray, leaf, d);
+                    }
+                } else {
+                    hit = hit_triangle(ray, s.tris + primitive, d);   // the box was tested exactly at the parent
+                }
+                if (hit) {
                     if (d < best_t) {
                         best_t = d;
                         best_i = primitive;
                         tie = false;
-                        if (d < hs.distance) cut = prune_cut(d);
+                        if (d < hs.distance) {
+                            cut = prune_cut(d);
+                            if (NODE32) cut32 = cut32_of(cut);
+                        }
                     } else if (d == best_t) {
                         tie = true;
                     }
                 }
-                if (sp == 0) {
-                    st = ST_SHADE;
-                } else {
-                    --sp;
-                    cur = stack[sp * BLOCK_THREADS];
-                    st = (cur < 0) ? ST_LEAF : ST_NODE;
-                }
+                pop();
             }
         } else {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS) { ++ws.node_phases; ws.node_lanes += __popcll(m_node); }
             if (st == ST_NODE) {
-                const PairNode* p = s.tri_tree.pairs + cur;
-                const int lref = p->left, rref = p->right;
-                double lmin, lmax, rmin, rmax;
-                slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
-                slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
-                const bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
-                const bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+                int lref, rref;
+                bool go_l, go_r, left_first;
+                float low_l = 0.0f, low_r = 0.0f;
+                if (NODE32) {
+                    const PairNode32* p = s.tri_pairs32 + cur;
+                    lref = p->left;
+                    rref = p->right;
+                    float up_l, up_r;
+                    slab32(r32, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], low_l, up_l);
+                    slab32(r32, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], low_r, up_r);
+                    go_l = !skip32(low_l, up_l, cut32);
+                    go_r = !skip32(low_r, up_r, cut32);
+                    left_first = !(low_r < low_l);
+                    if (STATS) {
+                        const PairNode* q = s.tri_tree.pairs + cur;
+                        double lmin, lmax, rmin, rmax;
+                        slab_finite(ray.o, inv, q->lbox[0], q->lbox[1], q->lbox[2], q->lbox[3], q->lbox[4], q->lbox[5], lmin, lmax);
+                        slab_finite(ray.o, inv, q->rbox[0], q->rbox[1], q->rbox[2], q->rbox[3], q->rbox[4], q->rbox[5], rmin, rmax);
+                        const bool exact_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
+                        const bool exact_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+                        ws.unsafe_skips += __popcll(__ballot((exact_l && !go_l) || (exact_r && !go_r)));
+                    }
+                } else {
+                    const PairNode* p = s.tri_tree.pairs + cur;
+                    lref = p->left;
+                    rref = p->right;
+                    double lmin, lmax, rmin, rmax;
+                    slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
+                    slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
+                    go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
+                    go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+                    left_first = !(rmin < lmin);
+                }
                 if (go_l && go_r) {
-                    const bool left_first = !(rmin < lmin);
-                    stack[sp * BLOCK_THREADS] = left_first ? rref : lref;
+                    stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
+                    if (NODE32) stack_low[sp * BLOCK_THREADS] = left_first ? low_r : low_l;
                     ++sp;
                     cur = left_first ? lref : rref;
-                } else if (go_l) {
-                    cur = lref;
-                } else if (go_r) {
-                    cur = rref;
-                } else if (sp == 0) {
-                    st = ST_SHADE;
+                    st = (cur < 0) ? ST_LEAF : ST_NODE;
+                } else if (go_l || go_r) {
+                    cur = go_l ? lref : rref;
+                    st = (cur < 0) ? ST_LEAF : ST_NODE;
                 } else {
-                    --sp;
-                    cur = stack[sp * BLOCK_THREADS];
+                    pop();
                 }
-                if (st != ST_SHADE) st = (cur < 0) ? ST_LEAF : ST_NODE;
             }
         }
     }
@@ -229,6 +305,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
         atomicAdd(stats + 2, ws.leaf_phases); atomicAdd(stats + 3, ws.leaf_lanes);
         atomicAdd(stats + 4, ws.shade_phases); atomicAdd(stats + 5, ws.shade_lanes);
         atomicAdd(stats + 6, ws.loops); atomicAdd(stats + 7, ws.paths);
+        atomicAdd(stats + 8, ws.unsafe_skips);
     }
 }
 
