@@ -293,7 +293,7 @@ struct PtScene {
     DeviceBuffer rgb, counters;
     size_t rgb_bytes = 0;
     bool albedo_bounded = false;        // every albedo finite with |albedo| <= 1
-    int compute_units = 0, blocks_per_cu = 0;
+    int compute_units = 0, blocks_per_cu = 0, occupancy_variant = -1;
     unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool has_stats = false;
     ~PtScene() {
@@ -439,7 +439,8 @@ unsigned grid_blocks(const PtFrame& f) {
     return static_cast<unsigned>((local_tiles(f) + (BLOCK_THREADS / 64) - 1) / (BLOCK_THREADS / 64));
 }
 
-// Tunables read once from the environment (measurement aids, not part of the interface).
+// Tunables read from the environment at every call (measurement and cross-checking aids, not
+// part of the interface): tests switch them between renders to compare the code paths.
 struct Tunables {
     bool force_pixels_kernel = false;   // PT_KERNEL=pixels: always the one-lane-per-pixel kernel
     bool stats = false;                 // PT_STATS=1: count phases and active lanes (slower)
@@ -460,10 +461,7 @@ struct Tunables {
         if (const char* v = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::atoi(v);
     }
 };
-const Tunables& tunables() {
-    static const Tunables t;
-    return t;
-}
+Tunables tunables() { return Tunables(); }
 
 int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
     hipLaunchKernelGGL(render_pixels_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream, scene->dev, frame_params(*frame), accum_device);
@@ -497,7 +495,7 @@ int trace_paths(bool stats_build, bool node32, unsigned blocks, hipStream_t stre
 
 // Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
 int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
-    const Tunables& t = tunables();
+    const Tunables t = tunables();
     const long long tiles_x = (frame->width + 7) / 8;
     const long long real_tiles = local_tiles(*frame);
     const size_t bytes_per_group = static_cast<size_t>(real_tiles) * 3 * CHUNK_PATHS * sizeof(double);
@@ -513,10 +511,12 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     }
     if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 256));
     const bool node32 = scene->dev.tri_pairs32 != nullptr && !t.force_f64_nodes;
-    if (scene->compute_units == 0) {
+    const int variant = (t.stats ? 2 : 0) + (node32 ? 1 : 0);
+    if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
         scene->compute_units = prop.multiProcessorCount;
+        scene->occupancy_variant = variant;
         int per_cu = 0;
         const int rc = trace_paths(t.stats, node32, 0, stream, scene->dev, FrameParams{}, WorkParams{}, nullptr, nullptr, nullptr, &per_cu);
         if (rc != PT_OK) return rc;
@@ -556,6 +556,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
 int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
     if (frame->row_begin == frame->row_end || frame->sample_count == 0 || grid_blocks(*frame) == 0) return PT_OK;
     HIP_TRY(hipSetDevice(scene->device));
+    scene->has_stats = false;
     HIP_TRY(hipEventRecord(scene->start, stream));
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.

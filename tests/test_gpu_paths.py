@@ -1,0 +1,110 @@
+"""Every code path of the GPU library must give the same bits.
+
+The library picks between two kernels (persistent wavefront / one lane per pixel), two inner-node
+precisions (conservative f32 / exact f64) and two search hierarchies (its own SAH rebuild / the
+reference's tree shape).  Each combination is rendered here and compared, bit for bit, with the
+CPU checker; environment switches (read by the library at every call) select the path.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODELS, same_bits
+from pathtracer_amd import ctypes_abi as abi
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ("PT_KERNEL", "PT_NODES", "PT_BVH", "PT_STATS", "PT_WORKSPACE_GB", "PT_SHADE_THRESHOLD", "PT_LEAF_THRESHOLD")
+
+
+@pytest.fixture
+def switches():
+    saved = {k: os.environ.pop(k, None) for k in SWITCHES}
+
+    def use(**values):
+        for k in SWITCHES:
+            os.environ.pop(k, None)
+        for k, v in values.items():
+            os.environ[k] = str(v)
+
+    yield use
+    for k in SWITCHES:
+        os.environ.pop(k, None)
+    for k, v in saved.items():
+        if v is not None:
+            os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def chess(api, orc):
+    host = api.HostScene(abi.PT_SCENE_CHESS32_MIXED, MODELS)
+    frame = host.frame(128, 72, sample_count=5, max_bounces=16)
+    expect = orc.scene_create(host.arrays()).render(frame, threads=8)
+    return host, frame, expect
+
+
+@pytest.mark.parametrize("bvh", ["sah", "reference"])
+@pytest.mark.parametrize("kernel,nodes", [("wave", "f32"), ("wave", "f64"), ("pixels", "f64")])
+def test_every_path_matches_the_checker(api, chess, switches, kernel, nodes, bvh):
+    host, frame, expect = chess
+    switches(PT_KERNEL=kernel, PT_NODES=nodes, PT_BVH=bvh)      # PT_BVH is read when the scene is created
+    device = api.DeviceScene.from_host(host)
+    assert same_bits(device.render(frame), expect)
+    tri, sph = device.primary_hits(frame)
+    switches()
+    tri_default, sph_default = api.DeviceScene.from_host(host).primary_hits(frame)
+    assert np.array_equal(tri, tri_default) and np.array_equal(sph, sph_default)
+
+
+def test_sample_batches_do_not_change_the_sum(api, chess, switches):
+    """A workspace too small for the whole sample range splits it into batches; each pixel's
+    samples are still added in ascending order."""
+    host, frame, expect = chess
+    switches(PT_WORKSPACE_GB="0.0001")       # one 16-sample group per batch
+    device = api.DeviceScene.from_host(host)
+    many = host.frame(64, 40, sample_count=37, max_bounces=16)
+    batched = device.render(many)
+    switches()
+    whole = api.DeviceScene.from_host(host).render(many)
+    assert same_bits(batched, whole)
+    assert (whole.reshape(-1, 4)[:, 3] == 37.0).all()
+
+
+def test_single_precision_nodes_never_skip_what_the_exact_test_accepts(api, switches):
+    """Profiling build: beside every conservative f32 box test the kernel evaluates the exact f64
+    test on the same node and counts boxes that f32 skipped but f64 accepts.  Must be zero."""
+    host = api.HostScene(abi.PT_SCENE_CHESS32, MODELS)
+    switches(PT_STATS=1)
+    device = api.DeviceScene.from_host(host)
+    device.render(host.frame(480, 270, sample_count=4))
+    stats = device.last_render_stats()
+    assert stats["paths"] == 480 * 272 * 4       # path slots are handed out per 8x8 tile: 270 rows round up to 272
+    assert stats["node_lanes"] > 10 * stats["paths"]
+    assert stats["unsafe_skips"] == 0
+
+
+def test_thresholds_only_change_scheduling(api, chess, switches):
+    host, frame, expect = chess
+    device = api.DeviceScene.from_host(host)
+    for shade, leaf in [(1, 1), (64, 64), (7, 33)]:
+        switches(PT_SHADE_THRESHOLD=shade, PT_LEAF_THRESHOLD=leaf)
+        assert same_bits(device.render(frame), expect)
+
+
+def test_unbounded_albedo_falls_back_to_the_pixel_kernel(api, orc, switches):
+    """|albedo| > 1 breaks the wavefront kernel's "colour is zero until the last vertex" premise;
+    such scenes must take the kernel that carries the colour explicitly and still match."""
+    from oracle.bindings import make_desc
+    host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, "pawn.triangles"))
+    arrays = host.arrays()
+    arrays["materials"]["v"][0][:3] = [1.5, 0.9, 2.0]
+    desc, keep = make_desc(arrays)
+    device = api.DeviceScene(desc, keepalive=keep)
+    frame = host.frame(64, 64, sample_count=3)
+    switches(PT_STATS=1)
+    accum = device.render(frame)
+    with pytest.raises(api.PathTracerError):
+        device.last_render_stats()           # no wavefront launch happened
+    switches()
+    assert same_bits(accum, orc.scene_create(arrays).render(frame, threads=4))
