@@ -41,6 +41,15 @@ def algorithmic_work(scene, width, height, max_bounces):
     return table.get(key, {}).get("per_sample"), key
 
 
+def hbm_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (or None)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    entry = json.load(open(path)).get(workload)
+    return None if entry is None else entry["trace_paths_kernel"]["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(host, width, height, spp, max_bounces):
     """The CPU renderer on this box's host cores, on a bounded sample of the same frame."""
     from oracle.bindings import OracleLib, RefLib, have_ref
@@ -132,8 +141,10 @@ def main():
         roofline, valu = None, None
         if work is not None:
             gbs = work["bytes"] * launch_samples / (launch_ms * 1e-3) / 1e9
+            workload = f"{args.scene} {w}x{h} {args.spp}spp depth{args.max_bounces}"
             roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "render_kernel", "kernel_ms": launch_ms,
+                        "traffic": hbm_traffic(workload) if world == 1 else None,
+                        "kernel": "trace_paths_kernel (+ sum_samples_kernel, <1%)", "kernel_ms": launch_ms,
                         "algorithmic_bytes_per_sample": work["bytes"], "work_table": work_key}
             tops = work["f64_ops"] * launch_samples / (launch_ms * 1e-3) / 1e12
             valu = {"bound": "fp64 valu (no FMA)", "achieved": tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tops/s",
