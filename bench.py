@@ -28,7 +28,8 @@ from pathtracer_amd.distributed import gather_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
 FP64_VALU_PEAK_TOPS = 39.3      # 78.6 TFLOP/s vector FP64 counts an FMA as two; the path may not fuse
-SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED}
+SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
+          "grid": abi.PT_SCENE_CHESS_GRID}
 
 
 def algorithmic_work(scene, width, height, max_bounces):
@@ -80,6 +81,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--max-bounces", type=int, default=50)
+    ap.add_argument("--grid", type=int, default=5, help="boards per side of --scene grid (5 -> 10.56 M triangles)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -98,7 +100,8 @@ def main():
 
     # ---- set-up, not timed: load models, build the BVH on the host, upload to HBM
     t0 = time.perf_counter()
-    host = api.HostScene(SCENES[args.scene], api.MODELS_DIR)
+    host = api.HostScene(SCENES[args.scene], api.MODELS_DIR, args.grid if args.scene == "grid" else 0)
+    scene_name = f"grid{args.grid}" if args.scene == "grid" else args.scene
     t1 = time.perf_counter()
     scene = api.DeviceScene.from_host(host, device=local_rank)
     t2 = time.perf_counter()
@@ -135,13 +138,13 @@ def main():
     if rank == 0:
         samples_per_step = w * h * args.spp
         value = samples_per_step * args.steps / seconds / 1e6
-        work, work_key = algorithmic_work(args.scene, w, h, args.max_bounces)
+        work, work_key = algorithmic_work(scene_name, w, h, args.max_bounces)
         launch_ms = float(np.mean(kernel_ms))
         launch_samples = samples_per_step / world            # what one launch (this rank's) processes
         roofline, valu = None, None
         if work is not None:
             gbs = work["bytes"] * launch_samples / (launch_ms * 1e-3) / 1e9
-            workload = f"{args.scene} {w}x{h} {args.spp}spp depth{args.max_bounces}"
+            workload = f"{scene_name} {w}x{h} {args.spp}spp depth{args.max_bounces}"
             roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "traffic": hbm_traffic(workload) if world == 1 else None,
                         "kernel": "trace_paths_kernel (+ sum_samples_kernel, <1%)", "kernel_ms": launch_ms,
@@ -155,7 +158,7 @@ def main():
             "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64",
             "data": "synthetic: deterministic chess-set scene built from the reference's six .triangles models; no random inputs",
-            "config": {"workload": f"{args.scene} {w}x{h} {args.spp}spp depth{args.max_bounces}",
+            "config": {"workload": f"{scene_name} {w}x{h} {args.spp}spp depth{args.max_bounces}",
                        "triangles": int(host.desc.triangle_count), "width": w, "height": h, "spp": args.spp,
                        "max_bounces": args.max_bounces,
                        "parallelism": f"rows in blocks of 8 round-robin over {world} GPU(s), scene replicated, one gather to rank 0"},

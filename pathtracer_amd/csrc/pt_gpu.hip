@@ -448,11 +448,13 @@ struct Tunables {
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
-    int shade_threshold = 16;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
-    int leaf_threshold = 16;
+    int shade_threshold = 28;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
+    int leaf_threshold = 24;
+    bool xcd_bands = false;             // PT_XCD=1: one chunk counter per XCD (tile rows dealt to the XCDs) instead of one for the chip
     Tunables() {
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
         if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
+        if (const char* v = std::getenv("PT_XCD")) xcd_bands = std::atoi(v) != 0;
         if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_LEAF_THRESHOLD")) leaf_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_KERNEL")) force_pixels_kernel = std::strcmp(v, "pixels") == 0;
@@ -509,7 +511,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         HIP_TRY(hipMalloc(&scene->rgb.p, need));
         scene->rgb_bytes = need;
     }
-    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 256));
+    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
     const bool node32 = scene->dev.tri_pairs32 != nullptr && !t.force_f64_nodes;
     const int variant = (t.stats ? 2 : 0) + (node32 ? 1 : 0);
     if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
@@ -523,8 +525,8 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
     }
     unsigned int* counter = static_cast<unsigned int*>(scene->counters.p);
-    unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(scene->counters.p) + 64);
-    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 256, stream));   // counter of the first batch + profiling counters
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(scene->counters.p) + 512);
+    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 1024, stream));   // chunk counters (one per 64-byte line) + profiling counters
 
     FrameParams fp = frame_params(*frame);
     const int sample_end = frame->sample_begin + frame->sample_count;
@@ -536,10 +538,12 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.tiles_x = static_cast<int>(tiles_x);
         wp.groups_per_tile = (fp.sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
         wp.chunk_count = real_tiles * wp.groups_per_tile;
+        wp.tile_rows = static_cast<int>(real_tiles / tiles_x);
+        wp.bands = t.xcd_bands ? 8 : 1;
         wp.shade_threshold = t.shade_threshold;
         wp.leaf_threshold = t.leaf_threshold;
         if (wp.chunk_count >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld chunks", wp.chunk_count);
-        if (!first) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), stream));
+        if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
         first = false;
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
                                                                           (wp.chunk_count + 3) / 4));
@@ -728,7 +732,7 @@ int pt_last_render_stats(PtScene* scene, uint64_t* out) {
     if (!scene->has_stats) return pt::fail(PT_ERR_UNSUPPORTED, "pt_last_render_stats: the last render did not run the wavefront kernel with PT_STATS=1");
     HIP_TRY(hipSetDevice(scene->device));
     HIP_TRY(hipEventSynchronize(scene->stop));
-    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->counters.p) + 64, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->counters.p) + 512, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -33,7 +33,9 @@ constexpr int WF_STACK_DEPTH = 24;     // trees up to 25 levels (2^24 leaves in 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
     int groups_per_tile;         // ceil(sample_count / SAMPLES_PER_CHUNK)
-    long long chunk_count;       // tiles_x * local row blocks * groups_per_tile
+    long long chunk_count;       // tiles_x * tile_rows * groups_per_tile
+    int tile_rows;               // rows of tiles rendered by this launch (this GPU's shard)
+    int bands;                   // 8: one chunk counter per XCD, tile row r belongs to band r % 8; 1: a single counter
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
 };
@@ -75,6 +77,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
     unsigned int chunk = 0;
     int chunk_next = 0, chunk_size = 0, chunk_row0 = 0, chunk_col0 = 0, chunk_sample0 = 0;
     bool work_left = true;
+    int bands_tried = 0;
+    // HW_REG_XCC_ID (hardware register 20, bits 3:0): which of the 8 XCDs this wave runs on
+    const int home_band = (w.bands > 1) ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % w.bands : 0;
     WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // per-lane path state
@@ -135,16 +140,30 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                 const unsigned long long m_need = __ballot(st == ST_NEED);
                 if (m_need == 0ull || !work_left) break;
                 if (chunk_next >= chunk_size) {
+                    // Chunks are dealt per band: tile row r belongs to band r % bands and each band has its own
+                    // counter.  A wave draws from the band of its XCD first, so the waves sharing an L2 work on
+                    // the same rows of tiles; when that band is empty it helps the next one.
+                    const unsigned int per_row = (unsigned int)w.tiles_x * (unsigned int)w.groups_per_tile;
+                    int band = -1;
                     unsigned int c = 0;
-                    if (lane == 0) c = atomicAdd(next_chunk, 1u);
-                    c = __builtin_amdgcn_readfirstlane(c);
-                    if ((long long)c >= w.chunk_count) { work_left = false; break; }
-                    chunk = c;
+                    while (bands_tried < w.bands) {
+                        const int b = (home_band + bands_tried) % w.bands;
+                        const unsigned int rows_in_band = (unsigned int)((w.tile_rows - b + w.bands - 1) / w.bands);
+                        unsigned int v = 0;
+                        if (lane == 0) v = atomicAdd(next_chunk + 16 * b, 1u);
+                        v = __builtin_amdgcn_readfirstlane(v);
+                        if (v < rows_in_band * per_row) { band = b; c = v; break; }
+                        ++bands_tried;                       // that band is finished for good
+                    }
+                    if (band < 0) { work_left = false; break; }
+                    const unsigned int band_row = c / per_row;
+                    const unsigned int rest = c - band_row * per_row;
+                    const unsigned int tile_col = rest / (unsigned int)w.groups_per_tile;
+                    const int group = (int)(rest - tile_col * (unsigned int)w.groups_per_tile);
+                    const unsigned int tile_row = band_row * (unsigned int)w.bands + (unsigned int)band;
+                    chunk = (tile_row * (unsigned int)w.tiles_x + tile_col) * (unsigned int)w.groups_per_tile + (unsigned int)group;
                     chunk_next = 0;
-                    const unsigned int tile = c / (unsigned int)w.groups_per_tile;
-                    const int group = (int)(c - tile * (unsigned int)w.groups_per_tile);
-                    const unsigned int tile_row = tile / (unsigned int)w.tiles_x;
-                    chunk_col0 = (int)(tile - tile_row * (unsigned int)w.tiles_x) * 8;
+                    chunk_col0 = (int)tile_col * 8;
                     chunk_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
                     chunk_sample0 = f.sample_begin + group * SAMPLES_PER_CHUNK;
                     chunk_size = 64 * min(SAMPLES_PER_CHUNK, f.sample_count - group * SAMPLES_PER_CHUNK);

@@ -6,18 +6,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pathtracer_amd import api, ctypes_abi as abi
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-kind = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED}[sys.argv[2] if len(sys.argv) > 2 else "chess32"]
-host = api.HostScene(kind, api.MODELS_DIR)
+name = sys.argv[2] if len(sys.argv) > 2 else "chess32"
+bounces = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+if name.startswith("grid"):
+    host = api.HostScene(abi.PT_SCENE_CHESS_GRID, api.MODELS_DIR, int(name[4:]))
+else:
+    host = api.HostScene({"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED}[name], api.MODELS_DIR)
+import time
+t0 = time.time()
 dev = api.DeviceScene.from_host(host)
+create_seconds = time.time() - t0
 w, h = 1920, 1080
 buf = torch.zeros(4 * w * h, dtype=torch.float64, device="cuda:0")
-fr = host.frame(w, h, sample_count=spp)
+fr = host.frame(w, h, sample_count=spp, max_bounces=bounces)
 for i in range(2):
     buf.zero_()
     dev.render_device(fr, buf.data_ptr())
     torch.cuda.synchronize()
 ms = dev.last_render_ms()
-out = {"spp": spp, "ms": ms, "msamples_per_s": w * h * spp / ms / 1e3}
+out = {"scene": name, "spp": spp, "max_bounces": bounces, "scene_create_s": create_seconds, "ms": ms, "msamples_per_s": w * h * spp / ms / 1e3}
 try:
     st = dev.last_render_stats()
     out["stats"] = st
