@@ -29,7 +29,7 @@ from pathtracer_amd.distributed import gather_rows  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
 FP64_VALU_PEAK_TOPS = 39.3      # 78.6 TFLOP/s vector FP64 counts an FMA as two; the path may not fuse
 SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
-          "grid": abi.PT_SCENE_CHESS_GRID}
+          "grid": abi.PT_SCENE_CHESS_GRID, "spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}
 
 
 def algorithmic_work(scene, width, height, max_bounces):

@@ -91,7 +91,8 @@ class _CpuLib:
         self.dll = C.CDLL(self.path)
         for name, restype in [("noise_1d", C.c_uint), ("noise_3d", C.c_uint), ("random_number", C.c_uint),
                               ("real_from_rng", C.c_double), ("degrees_to_radians", C.c_double),
-                              ("scene_create", C.c_void_p), ("model_scene", C.c_void_p)]:
+                              ("scene_create", C.c_void_p), ("model_scene", C.c_void_p),
+                              ("builtin_scene", C.c_void_p)]:
             self._call(name).restype = restype
         self._call("real_from_rng").argtypes = [C.c_uint]
         self._call("random_number").argtypes = [C.c_uint]
@@ -111,6 +112,7 @@ class _CpuLib:
         self._call("construct_triangle_bvh").argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         self._call("construct_sphere_bvh").argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         self._call("model_scene").argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        self._call("builtin_scene").argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         self._call("scene_create").argtypes = [C.c_void_p]
 
     def _call(self, name):
@@ -221,6 +223,14 @@ class _CpuLib:
         handle = self._call("model_scene")(os.fsencode(triangles_path), C.byref(cam), C.byref(aspect))
         if not handle:
             raise RuntimeError(f"model_scene({triangles_path}) failed")
+        return CpuScene(self, handle), cam, aspect.value
+
+    def builtin_scene(self, kind):
+        """kind 0 = the reference's random-spheres scene, 1 = its Cornell box."""
+        cam, aspect = PtCamera(), C.c_double(0.0)
+        handle = self._call("builtin_scene")(int(kind), C.byref(cam), C.byref(aspect))
+        if not handle:
+            raise RuntimeError(f"builtin_scene({kind}) failed")
         return CpuScene(self, handle), cam, aspect.value
 
 

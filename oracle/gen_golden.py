@@ -190,6 +190,19 @@ def main():
     tri, sphere = scene.primary_hits(big)
     g["chess6_640_hits"] = np.array([(tri >= 0).sum(), id_hash(tri), (sphere >= 0).sum()], np.uint64)
 
+    # ---- the reference's other two scenes: random spheres (src/main.cpp:516-625), Cornell box (:627-798)
+    for name, kind, (w_, h_) in (("spheres", 0, (72, 48)), ("cornell", 1, (48, 48))):
+        scene, cam, aspect = ref.builtin_scene(kind)
+        assert w_ / h_ == aspect
+        g[f"{name}_camera"] = np.frombuffer(bytes(cam), np.float64)
+        for key, value in scene.export().items():
+            g[f"{name}_scene_{key}"] = value.view(np.uint8) if value.dtype.fields else value
+        frame = ref.camera_frame(cam, aspect, w_, h_)
+        tri, sphere = scene.primary_hits(frame)
+        g[f"{name}_tri_hits"], g[f"{name}_sphere_hits"] = tri, sphere
+        frame.sample_count = 4
+        g[f"{name}_accum4"] = scene.render(frame)
+
     path = os.path.join(OUT, "reference_vectors.npz")
     np.savez_compressed(path, **g)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(g)} arrays")

@@ -686,6 +686,148 @@ OrcScene* orc_model_scene(const char* triangles_path, PtCamera* camera_out, doub
     return s;
 }
 
+namespace {
+PtMaterial make_material(int type, double a, double b, double c, double d) {
+    PtMaterial m;
+    std::memset(&m, 0, sizeof(m));
+    m.v[0] = a; m.v[1] = b; m.v[2] = c; m.v[3] = d;
+    m.type = type;
+    return m;
+}
+
+// Mat3 * Mat3, linear_algebra.cpp:50-66 (every product and sum kept, zeros included)
+void mat_mul(const PtMat3& a, const PtMat3& b, PtMat3* out) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out->rows[i][j] = a.rows[i][0] * b.rows[0][j] + a.rows[i][1] * b.rows[1][j] + a.rows[i][2] * b.rows[2][j];
+}
+
+PtVec3 mat_apply(const PtMat3& m, const PtVec3& v, const PtVec3& shift) {       // linear_algebra.cpp:42-48, then + shift
+    const double x = m.rows[0][0] * v.x + m.rows[0][1] * v.y + m.rows[0][2] * v.z;
+    const double y = m.rows[1][0] * v.x + m.rows[1][1] * v.y + m.rows[1][2] * v.z;
+    const double z = m.rows[2][0] * v.x + m.rows[2][1] * v.y + m.rows[2][2] * v.z;
+    return PtVec3{x + shift.x, y + shift.y, z + shift.z};
+}
+
+// the 12 triangles of the unit cube in the order +z, +x, -z, -x, +y, -y (src/main.cpp:643-667):
+// each face is a quad p0 p1 p2 p3 split as (p0 p1 p2), (p2 p3 p0); corners as bit masks x | y<<1 | z<<2
+const unsigned char CUBE_FACES[6][4] = {
+    {6, 4, 5, 7}, {7, 5, 1, 3}, {3, 1, 0, 2}, {2, 0, 4, 6}, {7, 3, 2, 6}, {4, 0, 1, 5}};
+
+void append_box(std::vector<PtTriangle>* out, double sx, double sy, double sz, double angle, const PtVec3& shift) {
+    PtMat3 scale_m, rot, both;
+    std::memset(&scale_m, 0, sizeof(scale_m));                                  // scaling_matrix, linear_algebra.cpp:72-79
+    scale_m.rows[0][0] = sx; scale_m.rows[1][1] = sy; scale_m.rows[2][2] = sz;
+    orc_rotation_matrix(angle, 0.0f, 1.0f, 0.0f, &rot);
+    mat_mul(scale_m, rot, &both);                                               // :669, :679
+    for (const unsigned char* face : {CUBE_FACES[0], CUBE_FACES[1], CUBE_FACES[2], CUBE_FACES[3], CUBE_FACES[4], CUBE_FACES[5]}) {
+        PtVec3 p[4];
+        for (int k = 0; k < 4; ++k) {
+            const PtVec3 corner{(double)(face[k] & 1), (double)((face[k] >> 1) & 1), (double)((face[k] >> 2) & 1)};
+            p[k] = mat_apply(both, corner, shift);                              // :671-673, :681-683
+        }
+        out->push_back(PtTriangle{p[0], p[1], p[2]});
+        out->push_back(PtTriangle{p[2], p[3], p[0]});
+    }
+}
+}  // namespace
+
+// The reference's two other built-in scenes: kind 0 = random spheres (src/main.cpp:516-625),
+// kind 1 = Cornell box (src/main.cpp:627-798).
+OrcScene* orc_builtin_scene(int kind, PtCamera* camera_out, double* aspect_out) {
+    std::vector<PtMaterial> mats;
+    std::vector<PtSphere> spheres;
+    std::vector<int> sphere_material;
+    std::vector<PtTriangle> tris;
+    std::vector<int> tri_material;
+    PtSceneDesc d;
+    std::memset(&d, 0, sizeof(d));
+    PtVec3 eye, target;
+    double fov_degrees, focus, aspect;
+    if (kind == 0) {
+        auto add = [&](const PtMaterial& m, double x, double y, double z, double r) {
+            sphere_material.push_back((int)mats.size());                        // sphere k uses material k
+            mats.push_back(m);
+            spheres.push_back(PtSphere{PtVec3{x, y, z}, r});
+        };
+        add(make_material(PT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0), 0.0f, -1000.0f, 0.0f, 1000.0f);   // :522-523
+        u32 r = 479001599u;                                                     // :527
+        auto next = [&]() { r = xorshift(r); return unit_real(r); };
+        for (int a = -11; a < 11; ++a) {
+            for (int b = -11; b < 11; ++b) {
+                const double choice = next();                                   // :530-537
+                const double dx = 0.9f * next();
+                const double dz = 0.9f * next();
+                PtMaterial m;
+                if (choice < 0.8f) {                                            // :542-562: product of two random colours
+                    double c1[3], c2[3];
+                    for (double& c : c1) c = next();
+                    for (double& c : c2) c = next();
+                    m = make_material(PT_LAMBERTIAN, c1[0] * c2[0], c1[1] * c2[1], c1[2] * c2[2], 0.0);
+                } else if (choice < 0.95f) {                                    // :563-576
+                    double c[3];
+                    for (double& x : c) x = 0.5f * next() + 0.5f;
+                    const double fuzz = next();
+                    m = make_material(PT_METAL, c[0], c[1], c[2], fuzz);
+                } else {
+                    m = make_material(PT_DIELECTRIC, 1.5f, 0.0, 0.0, 0.0);      // :578
+                }
+                add(m, (double)a + dx, 0.2f, (double)b + dz, 0.2f);             // :539-540
+            }
+        }
+        add(make_material(PT_DIELECTRIC, 1.5f, 0.0, 0.0, 0.0), 0.0f, 1.0f, 0.0f, 1.0f);             // :588-589
+        add(make_material(PT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0), -4.0f, 1.0f, 0.0f, 1.0f);          // :593-594
+        add(make_material(PT_METAL, 0.7f, 0.6f, 0.5f, 0.0f), 4.0f, 1.0f, 0.0f, 1.0f);               // :598-599
+        d.background_gradient_start = PtColour{1.0f, 1.0f, 1.0f};               // :614-615
+        d.background_gradient_end = PtColour{0.5f, 0.7f, 1.0f};
+        eye = PtVec3{13.0f, 2.0f, 3.0f}; target = PtVec3{0.0f, 0.0f, 0.0f};     // :618-625
+        fov_degrees = 20.0f; focus = 10.0f; aspect = 3.0f / 2.0f;               // :33
+    } else if (kind == 1) {
+        mats = {make_material(PT_LAMBERTIAN, 0.65f, 0.05f, 0.05f, 0.0),         // :627-633
+                make_material(PT_LAMBERTIAN, 0.73f, 0.73f, 0.73f, 0.0),
+                make_material(PT_LAMBERTIAN, 0.12f, 0.45f, 0.15f, 0.0),
+                make_material(PT_DIFFUSE_LIGHT, 1.0f, 1.0f, 1.0f, 15.0f),
+                make_material(PT_DIELECTRIC, 1.5f, 0.0, 0.0, 0.0)};
+        spheres = {PtSphere{PtVec3{183.0f, 240.0f, 169.0f}, 75.0f}};            // :635-639
+        sphere_material = {4};
+        // walls, floor, ceiling, back and light as quads p0 p1 p2 p3 -> (p0 p1 p2), (p2 p3 p0), :687-710
+        const double L = 555.0f;
+        const struct { double p[4][3]; int material; } quads[6] = {
+            {{{L, 0, 0}, {L, 0, L}, {L, L, L}, {L, L, 0}}, 2},
+            {{{0, 0, 0}, {0, L, 0}, {0, L, L}, {0, 0, L}}, 0},
+            {{{0, 0, 0}, {0, 0, L}, {L, 0, L}, {L, 0, 0}}, 1},
+            {{{0, L, 0}, {L, L, 0}, {L, L, L}, {0, L, L}}, 1},
+            {{{0, 0, L}, {0, L, L}, {L, L, L}, {L, 0, L}}, 1},
+            {{{213.0f, 554.0f, 227.0f}, {343.0f, 554.0f, 227.0f}, {343.0f, 554.0f, 332.0f}, {213.0f, 554.0f, 332.0f}}, 3}};
+        for (const auto& q : quads) {
+            PtVec3 p[4];
+            for (int k = 0; k < 4; ++k) p[k] = PtVec3{q.p[k][0], q.p[k][1], q.p[k][2]};
+            tris.push_back(PtTriangle{p[0], p[1], p[2]});
+            tris.push_back(PtTriangle{p[2], p[3], p[0]});
+            tri_material.push_back(q.material);                                 // :751-768
+            tri_material.push_back(q.material);
+        }
+        const double pi = 3.14159265358979323846264f;
+        append_box(&tris, 165.0f, 165.0f, 165.0f, -pi / 10.0f, PtVec3{130.0f, 0.0f, 65.0f});        // :669-673
+        append_box(&tris, 165.0f, 330.0f, 165.0f, pi / 12.0f, PtVec3{265.0f, 0.0f, 295.0f});        // :679-683
+        tri_material.resize(tris.size(), 1);                                    // :770-774
+        d.background_gradient_start = PtColour{0.0f, 0.0f, 0.0f};               // :787-788
+        d.background_gradient_end = PtColour{0.0f, 0.0f, 0.0f};
+        eye = PtVec3{278.0f, 278.0f, -800.0f}; target = PtVec3{278.0f, 278.0f, 0.0f};               // :791-798
+        fov_degrees = 40.0f; focus = 0.0; aspect = 1.0f;                        // focus = camera distance; :34
+    } else {
+        return nullptr;
+    }
+    d.materials = mats.data(); d.material_count = (int)mats.size();
+    d.spheres = spheres.data(); d.sphere_count = (int)spheres.size(); d.sphere_material_indices = sphere_material.data();
+    d.triangles = tris.empty() ? nullptr : tris.data(); d.triangle_count = (int)tris.size();
+    d.triangle_material_indices = tris.empty() ? nullptr : tri_material.data();
+    OrcScene* s = orc_scene_create(&d);
+    if (camera_out) orc_camera_look_at(&eye, &target, orc_degrees_to_radians(fov_degrees), 0.1f, focus, camera_out);
+    if (aspect_out) *aspect_out = aspect;
+    return s;
+}
+
 void orc_scene_destroy(OrcScene* s) { delete s; }
 
 int orc_scene_counts(const OrcScene* s, int* out) {

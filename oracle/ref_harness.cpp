@@ -342,6 +342,158 @@ RefScene* ref_model_scene(const char* triangles_path, PtCamera* camera_out, doub
     return s;
 }
 
+// The reference's two other built-in scenes, restated from src/main.cpp (which cannot be compiled
+// here) with the reference's own constructors, hashing and matrix code.  kind 0 = random spheres
+// (src/main.cpp:516-625), kind 1 = Cornell box (src/main.cpp:627-798).
+RefScene* ref_builtin_scene(int kind, PtCamera* camera_out, double* aspect_out) {
+    RefScene* s = new RefScene();
+    Camera camera = {};
+    Colour bg_start{}, bg_end{};
+    if (kind == 0) {
+        static constexpr int SPHERE_COUNT = 22 * 22 + 4;                                            // :516
+        s->materials.resize(SPHERE_COUNT);
+        s->spheres.resize(SPHERE_COUNT);
+        s->sphere_material_indices.resize(SPHERE_COUNT);
+        Material* materials = s->materials.data();
+        Sphere* spheres = s->spheres.data();
+        int* sphere_material_indices = s->sphere_material_indices.data();
+
+        int sphere_index = 0;
+        materials[sphere_index] = construct_lambertian_material(Colour{0.5f, 0.5f, 0.5f});         // :522
+        spheres[sphere_index] = Sphere{Vec3{0.0f, -1000.0f, 0.0f}, 1000.0f};
+        sphere_material_indices[sphere_index] = sphere_index;
+        ++sphere_index;
+
+        u32 rng = 479001599;                                                                        // :527
+        for (int a = -11; a < 11; ++a) {
+            for (int b = -11; b < 11; ++b) {
+                rng = random_number(rng);
+                const real material_choice = real_from_rng(rng);
+                rng = random_number(rng);
+                const real x_offset = 0.9f * real_from_rng(rng);
+                rng = random_number(rng);
+                const real z_offset = 0.9f * real_from_rng(rng);
+                const Vec3 sphere_centre{static_cast<real>(a) + x_offset, 0.2f, static_cast<real>(b) + z_offset};
+                spheres[sphere_index] = Sphere{sphere_centre, 0.2f};
+                if (material_choice < 0.8f) {                                                       // :542
+                    rng = random_number(rng); const real colour_1_r = real_from_rng(rng);
+                    rng = random_number(rng); const real colour_1_g = real_from_rng(rng);
+                    rng = random_number(rng); const real colour_1_b = real_from_rng(rng);
+                    const Colour colour_1{colour_1_r, colour_1_g, colour_1_b};
+                    rng = random_number(rng); const real colour_2_r = real_from_rng(rng);
+                    rng = random_number(rng); const real colour_2_g = real_from_rng(rng);
+                    rng = random_number(rng); const real colour_2_b = real_from_rng(rng);
+                    const Colour colour_2{colour_2_r, colour_2_g, colour_2_b};
+                    const Colour albedo = colour_1 * colour_2;
+                    materials[sphere_index] = construct_lambertian_material(albedo);
+                } else if (material_choice < 0.95f) {                                               // :563
+                    rng = random_number(rng); const real colour_r = 0.5f * real_from_rng(rng) + 0.5f;
+                    rng = random_number(rng); const real colour_g = 0.5f * real_from_rng(rng) + 0.5f;
+                    rng = random_number(rng); const real colour_b = 0.5f * real_from_rng(rng) + 0.5f;
+                    const Colour albedo{colour_r, colour_g, colour_b};
+                    rng = random_number(rng);
+                    const real fuzziness = real_from_rng(rng);
+                    materials[sphere_index] = construct_metal_material(albedo, fuzziness);
+                } else {
+                    materials[sphere_index] = construct_dielectric_material(1.5f);
+                }
+                sphere_material_indices[sphere_index] = sphere_index;
+                ++sphere_index;
+            }
+        }
+        assert(sphere_index == SPHERE_COUNT - 3);                                                   // :586
+        materials[sphere_index] = construct_dielectric_material(1.5f);
+        spheres[sphere_index] = Sphere{Vec3{0.0f, 1.0f, 0.0f}, 1.0f};
+        sphere_material_indices[sphere_index] = sphere_index;
+        ++sphere_index;
+        materials[sphere_index] = construct_lambertian_material(Colour{0.4f, 0.2f, 0.1f});
+        spheres[sphere_index] = Sphere{Vec3{-4.0f, 1.0f, 0.0f}, 1.0f};
+        sphere_material_indices[sphere_index] = sphere_index;
+        ++sphere_index;
+        materials[sphere_index] = construct_metal_material(Colour{0.7f, 0.6f, 0.5f}, 0.0f);
+        spheres[sphere_index] = Sphere{Vec3{4.0f, 1.0f, 0.0f}, 1.0f};
+        sphere_material_indices[sphere_index] = sphere_index;
+        ++sphere_index;
+        assert(sphere_index == SPHERE_COUNT);                                                       // :603
+        bg_start = Colour{1.0f, 1.0f, 1.0f};                                                        // :614-615
+        bg_end = Colour{0.5f, 0.7f, 1.0f};
+
+        const Vec3 sphere_camera_start_position{13.0f, 2.0f, 3.0f};                                 // :618-625
+        camera.target = Vec3{0.0f, 0.0f, 0.0f};
+        camera.orientation = look_at_matrix(sphere_camera_start_position, camera.target);
+        camera.distance = magnitude(sphere_camera_start_position - camera.target);
+        camera.fov_y = degrees_to_radians(20.0f);
+        camera.aperture = 0.1f;
+        camera.focus_distance = 10.0f;
+        if (aspect_out != nullptr) *aspect_out = 3.0f / 2.0f;                                       // :33
+    } else {
+        s->materials = {                                                                            // :627-633
+            construct_lambertian_material(Colour{0.65f, 0.05f, 0.05f}),
+            construct_lambertian_material(Colour{0.73f, 0.73f, 0.73f}),
+            construct_lambertian_material(Colour{0.12f, 0.45f, 0.15f}),
+            construct_diffuse_light_material(Colour{1.0f, 1.0f, 1.0f}, 15.0f),
+            construct_dielectric_material(1.5f)
+        };
+        s->spheres = {Sphere{Vec3{183.0f, 240.0f, 169.0f}, 75.0f}};                                 // :635-637
+        s->sphere_material_indices = {4};                                                           // :639
+
+        const Vec3 unit_box_vertices[] = {                                                          // :643-667
+            Vec3{0.0f, 1.0f, 1.0f}, Vec3{0.0f, 0.0f, 1.0f}, Vec3{1.0f, 0.0f, 1.0f},
+            Vec3{1.0f, 0.0f, 1.0f}, Vec3{1.0f, 1.0f, 1.0f}, Vec3{0.0f, 1.0f, 1.0f},
+            Vec3{1.0f, 1.0f, 1.0f}, Vec3{1.0f, 0.0f, 1.0f}, Vec3{1.0f, 0.0f, 0.0f},
+            Vec3{1.0f, 0.0f, 0.0f}, Vec3{1.0f, 1.0f, 0.0f}, Vec3{1.0f, 1.0f, 1.0f},
+            Vec3{1.0f, 1.0f, 0.0f}, Vec3{1.0f, 0.0f, 0.0f}, Vec3{0.0f, 0.0f, 0.0f},
+            Vec3{0.0f, 0.0f, 0.0f}, Vec3{0.0f, 1.0f, 0.0f}, Vec3{1.0f, 1.0f, 0.0f},
+            Vec3{0.0f, 1.0f, 0.0f}, Vec3{0.0f, 0.0f, 0.0f}, Vec3{0.0f, 0.0f, 1.0f},
+            Vec3{0.0f, 0.0f, 1.0f}, Vec3{0.0f, 1.0f, 1.0f}, Vec3{0.0f, 1.0f, 0.0f},
+            Vec3{1.0f, 1.0f, 1.0f}, Vec3{1.0f, 1.0f, 0.0f}, Vec3{0.0f, 1.0f, 0.0f},
+            Vec3{0.0f, 1.0f, 0.0f}, Vec3{0.0f, 1.0f, 1.0f}, Vec3{1.0f, 1.0f, 1.0f},
+            Vec3{0.0f, 0.0f, 1.0f}, Vec3{0.0f, 0.0f, 0.0f}, Vec3{1.0f, 0.0f, 0.0f},
+            Vec3{1.0f, 0.0f, 0.0f}, Vec3{1.0f, 0.0f, 1.0f}, Vec3{0.0f, 0.0f, 1.0f}
+        };
+        const Mat3 right_box_transform = scaling_matrix(165.0f, 165.0f, 165.0f) * rotation_matrix(-PI / 10.0f, 0.0f, 1.0f, 0.0f);   // :669
+        Vec3 right_box_vertices[36] = {};
+        for (int i = 0; i < 36; ++i) right_box_vertices[i] = right_box_transform * unit_box_vertices[i] + Vec3{130.0f, 0.0f, 65.0f};
+        const Mat3 left_box_transform = scaling_matrix(165.0f, 330.0f, 165.0f) * rotation_matrix(PI / 12.0f, 0.0f, 1.0f, 0.0f);      // :679
+        Vec3 left_box_vertices[36] = {};
+        for (int i = 0; i < 36; ++i) left_box_vertices[i] = left_box_transform * unit_box_vertices[i] + Vec3{265.0f, 0.0f, 295.0f};
+
+        s->triangles = {                                                                            // :687-749
+            Triangle{Vec3{555.0f, 0.0f, 0.0f}, Vec3{555.0f, 0.0f, 555.0f}, Vec3{555.0f, 555.0f, 555.0f}},
+            Triangle{Vec3{555.0f, 555.0f, 555.0f}, Vec3{555.0f, 555.0f, 0.0f}, Vec3{555.0f, 0.0f, 0.0f}},
+            Triangle{Vec3{0.0f, 0.0f, 0.0f}, Vec3{0.0f, 555.0f, 0.0f}, Vec3{0.0f, 555.0f, 555.0f}},
+            Triangle{Vec3{0.0f, 555.0f, 555.0f}, Vec3{0.0f, 0.0f, 555.0f}, Vec3{0.0f, 0.0f, 0.0f}},
+            Triangle{Vec3{0.0f, 0.0f, 0.0f}, Vec3{0.0f, 0.0f, 555.0f}, Vec3{555.0f, 0.0f, 555.0f}},
+            Triangle{Vec3{555.0f, 0.0f, 555.0f}, Vec3{555.0f, 0.0f, 0.0f}, Vec3{0.0f, 0.0f, 0.0f}},
+            Triangle{Vec3{0.0f, 555.0f, 0.0f}, Vec3{555.0f, 555.0f, 0.0f}, Vec3{555.0f, 555.0f, 555.0f}},
+            Triangle{Vec3{555.0f, 555.0f, 555.0f}, Vec3{0.0f, 555.0f, 555.0f}, Vec3{0.0f, 555.0f, 0.0f}},
+            Triangle{Vec3{0.0f, 0.0f, 555.0f}, Vec3{0.0f, 555.0f, 555.0f}, Vec3{555.0f, 555.0f, 555.0f}},
+            Triangle{Vec3{555.0f, 555.0f, 555.0f}, Vec3{555.0f, 0.0f, 555.0f}, Vec3{0.0f, 0.0f, 555.0f}},
+            Triangle{Vec3{213.0f, 554.0f, 227.0f}, Vec3{343.0f, 554.0f, 227.0f}, Vec3{343.0f, 554.0f, 332.0f}},
+            Triangle{Vec3{343.0f, 554.0f, 332.0f}, Vec3{213.0f, 554.0f, 332.0f}, Vec3{213.0f, 554.0f, 227.0f}}
+        };
+        for (int i = 0; i < 36; i += 3) s->triangles.push_back(Triangle{right_box_vertices[i], right_box_vertices[i + 1], right_box_vertices[i + 2]});
+        for (int i = 0; i < 36; i += 3) s->triangles.push_back(Triangle{left_box_vertices[i], left_box_vertices[i + 1], left_box_vertices[i + 2]});
+        s->triangle_material_indices = {2, 2, 0, 0, 1, 1, 1, 1, 1, 1, 3, 3,                         // :751-775
+                                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        bg_start = Colour{0.0f, 0.0f, 0.0f};                                                        // :787-788
+        bg_end = Colour{0.0f, 0.0f, 0.0f};
+
+        const Vec3 cornell_camera_start_position{278.0f, 278.0f, -800.0f};                          // :791-798
+        camera.target = Vec3{278.0f, 278.0f, 0.0f};
+        camera.orientation = look_at_matrix(cornell_camera_start_position, camera.target);
+        camera.distance = magnitude(cornell_camera_start_position - camera.target);
+        camera.fov_y = degrees_to_radians(40.0f);
+        camera.aperture = 0.1f;
+        camera.focus_distance = camera.distance;
+        if (aspect_out != nullptr) *aspect_out = 1.0f;                                              // :34
+    }
+    finish_scene(s, bg_start, bg_end);
+    if (camera_out != nullptr) std::memcpy(camera_out, &camera, sizeof(camera));
+    return s;
+}
+
 void ref_scene_destroy(RefScene* s) { delete s; }
 
 int ref_scene_counts(const RefScene* s, int* out /* materials, spheres, sphere nodes, triangles, triangle nodes */) {

@@ -1,8 +1,10 @@
 // Built-in host scenes.
 //
 // PT_SCENE_MODEL restates the reference's active scene (src/main.cpp:800-840) with the model
-// file as a parameter.  The reference defines no multi-piece scene, so the chess scenes are
-// this library's own: fixed, seedless constructions over the reference's six model files.
+// file as a parameter; PT_SCENE_RANDOM_SPHERES and PT_SCENE_CORNELL_BOX are the reference's two
+// other scenes (src/main.cpp:516-625, 627-798).  The reference defines no multi-piece scene, so
+// the chess scenes are this library's own: fixed, seedless constructions over the reference's
+// six model files.
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -58,9 +60,102 @@ int finish(PtHostScene* scene) {
     return PT_OK;
 }
 
-void set_camera(PtHostScene* scene, PtVec3 position, PtVec3 target, double fov_degrees, double aspect) {
-    pt_camera_look_at(&position, &target, degrees_to_radians(fov_degrees), 0.1f, 0.0, &scene->camera);
+// `focus` <= 0 focuses on the target (focus_distance = camera distance).
+void set_camera(PtHostScene* scene, PtVec3 position, PtVec3 target, double fov_degrees, double aspect, double focus = 0.0) {
+    pt_camera_look_at(&position, &target, degrees_to_radians(fov_degrees), 0.1f, focus, &scene->camera);
     scene->aspect_ratio = aspect;
+}
+
+// src/rng.cpp:63-69 and :30-32: the reference's xorshift32 step and its map to [0, 1]
+struct SceneRng {
+    uint32_t state;
+    double next() {
+        state ^= state << 13;
+        state ^= state >> 17;
+        state ^= state << 5;
+        return static_cast<double>(state) / 4294967295.0;
+    }
+};
+
+// 22 x 22 small spheres with hashed positions and materials on a 1000-unit ground sphere, plus
+// three unit spheres (glass, brown, mirror); sphere k uses material k (src/main.cpp:516-625).
+int build_random_spheres(PtHostScene* scene) {
+    auto place = [scene](const PtMaterial& material, PtVec3 centre, double radius) {
+        scene->sphere_material_indices.push_back(static_cast<int>(scene->materials.size()));
+        scene->materials.push_back(material);
+        scene->spheres.push_back(PtSphere{centre, radius});
+    };
+    place(lambertian(0.5f, 0.5f, 0.5f), PtVec3{0.0f, -1000.0f, 0.0f}, 1000.0f);         // :522-523
+    SceneRng rng{479001599u};                                                            // :527
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            const double material_choice = rng.next();                                   // :530-531
+            const double x_offset = 0.9f * rng.next();                                   // :533-537
+            const double z_offset = 0.9f * rng.next();
+            const PtVec3 centre{static_cast<double>(a) + x_offset, 0.2f, static_cast<double>(b) + z_offset};
+            if (material_choice < 0.8f) {                                                // :542-562
+                const double r1 = rng.next(), g1 = rng.next(), b1 = rng.next();
+                const double r2 = rng.next(), g2 = rng.next(), b2 = rng.next();
+                place(lambertian(r1 * r2, g1 * g2, b1 * b2), centre, 0.2f);
+            } else if (material_choice < 0.95f) {                                        // :563-576
+                const double r = 0.5f * rng.next() + 0.5f;
+                const double g = 0.5f * rng.next() + 0.5f;
+                const double bl = 0.5f * rng.next() + 0.5f;
+                const double fuzziness = rng.next();
+                place(metal(r, g, bl, fuzziness), centre, 0.2f);
+            } else {
+                place(dielectric(1.5f), centre, 0.2f);                                   // :578
+            }
+        }
+    }
+    place(dielectric(1.5f), PtVec3{0.0f, 1.0f, 0.0f}, 1.0f);                             // :588-589
+    place(lambertian(0.4f, 0.2f, 0.1f), PtVec3{-4.0f, 1.0f, 0.0f}, 1.0f);                // :593-594
+    place(metal(0.7f, 0.6f, 0.5f, 0.0f), PtVec3{4.0f, 1.0f, 0.0f}, 1.0f);                // :598-599
+    scene->background_start = PtColour{1.0f, 1.0f, 1.0f};                                // :614-615
+    scene->background_end = PtColour{0.5f, 0.7f, 1.0f};
+    set_camera(scene, PtVec3{13.0f, 2.0f, 3.0f}, PtVec3{0.0f, 0.0f, 0.0f}, 20.0f, 3.0f / 2.0f, 10.0f);   // :618-625, :33
+    return finish(scene);
+}
+
+void append_quad(PtHostScene* scene, PtVec3 p0, PtVec3 p1, PtVec3 p2, PtVec3 p3, int material) {
+    scene->triangles.push_back(PtTriangle{p0, p1, p2});
+    scene->triangles.push_back(PtTriangle{p2, p3, p0});
+    scene->triangle_material_indices.push_back(material);
+    scene->triangle_material_indices.push_back(material);
+}
+
+// A unit cube scaled, turned about y and shifted, as 12 triangles in the reference's face
+// order +z, +x, -z, -x, +y, -y (src/main.cpp:643-683).  Corner c has x = c&1, y = c>>1&1, z = c>>2.
+void append_cornell_box(PtHostScene* scene, double height, double angle, PtVec3 shift, int material) {
+    static const int FACES[6][4] = {{6, 4, 5, 7}, {7, 5, 1, 3}, {3, 1, 0, 2}, {2, 0, 4, 6}, {7, 3, 2, 6}, {4, 0, 1, 5}};
+    const PtMat3 m = multiply(scaling(165.0f, height, 165.0f), rotation(angle, 0.0f, 1.0f, 0.0f));
+    PtVec3 corner[8];
+    for (int c = 0; c < 8; ++c) {
+        corner[c] = transform(m, PtVec3{static_cast<double>(c & 1), static_cast<double>((c >> 1) & 1), static_cast<double>(c >> 2)}) + shift;
+    }
+    for (const int (&f)[4] : FACES) append_quad(scene, corner[f[0]], corner[f[1]], corner[f[2]], corner[f[3]], material);
+}
+
+// src/main.cpp:627-798
+int build_cornell_box(PtHostScene* scene) {
+    enum { RED = 0, WHITE = 1, GREEN = 2, LIGHT = 3, GLASS = 4 };
+    scene->materials = {lambertian(0.65f, 0.05f, 0.05f), lambertian(0.73f, 0.73f, 0.73f), lambertian(0.12f, 0.45f, 0.15f),
+                        diffuse_light(1.0f, 1.0f, 1.0f, 15.0f), dielectric(1.5f)};       // :627-633
+    scene->spheres = {PtSphere{PtVec3{183.0f, 240.0f, 169.0f}, 75.0f}};                  // :635-639
+    scene->sphere_material_indices = {GLASS};
+    const double e = 555.0f;
+    append_quad(scene, PtVec3{e, 0, 0}, PtVec3{e, 0, e}, PtVec3{e, e, e}, PtVec3{e, e, 0}, GREEN);    // :689-690
+    append_quad(scene, PtVec3{0, 0, 0}, PtVec3{0, e, 0}, PtVec3{0, e, e}, PtVec3{0, 0, e}, RED);      // :693-694
+    append_quad(scene, PtVec3{0, 0, 0}, PtVec3{0, 0, e}, PtVec3{e, 0, e}, PtVec3{e, 0, 0}, WHITE);    // :697-698 floor
+    append_quad(scene, PtVec3{0, e, 0}, PtVec3{e, e, 0}, PtVec3{e, e, e}, PtVec3{0, e, e}, WHITE);    // :701-702 ceiling
+    append_quad(scene, PtVec3{0, 0, e}, PtVec3{0, e, e}, PtVec3{e, e, e}, PtVec3{e, 0, e}, WHITE);    // :705-706 back
+    append_quad(scene, PtVec3{213.0f, 554.0f, 227.0f}, PtVec3{343.0f, 554.0f, 227.0f}, PtVec3{343.0f, 554.0f, 332.0f},
+                PtVec3{213.0f, 554.0f, 332.0f}, LIGHT);                                                // :709-710
+    append_cornell_box(scene, 165.0f, -PI_F / 10.0f, PtVec3{130.0f, 0.0f, 65.0f}, WHITE);             // :669-673
+    append_cornell_box(scene, 330.0f, PI_F / 12.0f, PtVec3{265.0f, 0.0f, 295.0f}, WHITE);             // :679-683
+    scene->background_start = scene->background_end = PtColour{0.0f, 0.0f, 0.0f};       // :787-788
+    set_camera(scene, PtVec3{278.0f, 278.0f, -800.0f}, PtVec3{278.0f, 278.0f, 0.0f}, 40.0f, 1.0f);    // :791-798, :34
+    return finish(scene);
 }
 
 // src/main.cpp:800-840
@@ -218,6 +313,12 @@ int pt_host_scene_build(int32_t kind, const char* path, int32_t param, PtHostSce
         if (path == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "chess scenes need the model directory");
         if (param < 1 || param > 8) return fail(PT_ERR_INVALID_ARGUMENT, "PT_SCENE_CHESS_GRID: grid_n must be in 1..8, got %d", param);
         rc = build_chess32(path, false, param, scene.get());
+        break;
+    case PT_SCENE_RANDOM_SPHERES:
+        rc = build_random_spheres(scene.get());
+        break;
+    case PT_SCENE_CORNELL_BOX:
+        rc = build_cornell_box(scene.get());
         break;
     default:
         return fail(PT_ERR_UNSUPPORTED, "pt_host_scene_build: unknown scene kind %d", kind);

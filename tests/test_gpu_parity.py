@@ -27,6 +27,10 @@ def scenes(api, orc):
         if name not in cache:
             if name in ("rook", "pawn", "knight"):
                 host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, name + ".triangles"))
+            elif name in ("spheres", "cornell"):
+                host = api.HostScene({"spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}[name])
+            elif name == "grid2":
+                host = api.HostScene(abi.PT_SCENE_CHESS_GRID, MODELS, 2)
             else:
                 kind = {"chess6": abi.PT_SCENE_CHESS6_ROW, "chess32": abi.PT_SCENE_CHESS32, "mixed": abi.PT_SCENE_CHESS32_MIXED}[name]
                 host = api.HostScene(kind, MODELS)
@@ -129,7 +133,23 @@ def test_accumulation_buffer_chess6(scenes, golden):
     assert same_bits(accum, golden["chess6_accum4"])
 
 
+@pytest.mark.parametrize("name,size", [("spheres", (72, 48)), ("cornell", (48, 48))])
+def test_reference_builtin_scenes(scenes, golden, name, size):
+    """The reference's random-spheres and Cornell-box scenes (src/main.cpp:516-625, 627-798):
+    488 spheres in a sphere BVH with no triangles at all; triangles, an area light and a glass sphere."""
+    host, device, _ = scenes(name)
+    frame = host.frame(*size)
+    tri, sph = device.primary_hits(frame)
+    assert np.array_equal(tri, golden[f"{name}_tri_hits"]) and np.array_equal(sph, golden[f"{name}_sphere_hits"])
+    frame.sample_count = 4
+    assert same_bits(device.render(frame), golden[f"{name}_accum4"])
+
+
 @pytest.mark.parametrize("name,size,spp,bounces", [
+    ("spheres", (150, 100), 3, 50),    # depth-of-field camera, hundreds of spheres, sky background
+    ("cornell", (100, 100), 6, 50),
+    ("cornell", (41, 41), 2, 5),
+    ("grid2", (128, 72), 2, 50),       # four boards, 1.69 M triangles
     ("chess32", (160, 90), 4, 50),
     ("chess32", (96, 54), 3, 16),
     ("mixed", (160, 90), 4, 16),       # metal, glass, sky: every scatter branch and long paths

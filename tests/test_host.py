@@ -99,6 +99,21 @@ def test_model_scene_is_the_reference_scene(api, orc, golden):
             assert ours[key].tobytes() == theirs[key].tobytes(), (name, key)
 
 
+@pytest.mark.parametrize("name,kind,index", [("spheres", abi.PT_SCENE_RANDOM_SPHERES, 0), ("cornell", abi.PT_SCENE_CORNELL_BOX, 1)])
+def test_reference_builtin_scenes(api, orc, golden, name, kind, index):
+    """src/main.cpp:516-625 (random spheres) and :627-798 (Cornell box): the library's scene arrays,
+    BVHs and cameras against the CPU restatement and against the arrays the reference's own code made."""
+    host = api.HostScene(kind)
+    checker, cam, aspect = orc.builtin_scene(index)
+    assert bytes(host.camera) == bytes(cam) == golden[f"{name}_camera"].tobytes()
+    assert host.aspect_ratio == aspect == (1.5 if name == "spheres" else 1.0)
+    ours, theirs = host.arrays(), checker.export()
+    for key in theirs:
+        assert ours[key].tobytes() == theirs[key].tobytes() == golden[f"{name}_scene_{key}"].tobytes(), (name, key)
+    assert len(ours["spheres"]) == (488 if name == "spheres" else 1)
+    assert len(ours["triangles"]) == (0 if name == "spheres" else 36)
+
+
 def test_chess_scenes(api, golden):
     six = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
     arrays = six.arrays()

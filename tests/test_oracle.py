@@ -69,6 +69,19 @@ def test_bvh_build_matches_reference(orc, golden):
     assert nodes.tobytes() == golden["sphere_bvh_out"].tobytes()
 
 
+@pytest.mark.parametrize("name,index,size", [("spheres", 0, (72, 48)), ("cornell", 1, (48, 48))])
+def test_reference_builtin_scene_render(orc, golden, name, index, size):
+    """The restatement's own construction of src/main.cpp:516-625 / :627-798 rendered by the
+    restatement, against the reference-made accumulation buffer (metal, glass, sky, area light)."""
+    scene, cam, aspect = orc.builtin_scene(index)
+    assert bytes(cam) == golden[f"{name}_camera"].tobytes()
+    frame = orc.camera_frame(cam, aspect, *size)
+    tri, sph = scene.primary_hits(frame)
+    assert np.array_equal(tri, golden[f"{name}_tri_hits"]) and np.array_equal(sph, golden[f"{name}_sphere_hits"])
+    frame.sample_count = 4
+    assert same_bits(scene.render(frame), golden[f"{name}_accum4"])
+
+
 @pytest.mark.parametrize("name,size", [("rook", (64, 48)), ("pawn", (64, 36))])
 def test_model_scene_render(orc, golden, name, size):
     scene, cam, aspect = orc.model_scene(os.path.join(MODELS, name + ".triangles"))
