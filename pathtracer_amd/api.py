@@ -234,7 +234,7 @@ class DeviceScene:
         out = np.zeros(16, np.uint64)
         check(lib().pt_last_render_stats(self.handle, ptr(out)))
         names = ["node_phases", "node_lanes", "leaf_phases", "leaf_lanes", "shade_phases", "shade_lanes", "loops", "paths",
-                 "unsafe_skips"]
+                 "unsafe_skips", "t_node", "t_leaf", "t_shade", "t_refill", "t_setup", "t_total"]
         return dict(zip(names, out.tolist()))
 
     def primary_hits(self, frame):

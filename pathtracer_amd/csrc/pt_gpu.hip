@@ -443,7 +443,7 @@ unsigned grid_blocks(const PtFrame& f) {
 // part of the interface): tests switch them between renders to compare the code paths.
 struct Tunables {
     bool force_pixels_kernel = false;   // PT_KERNEL=pixels: always the one-lane-per-pixel kernel
-    bool stats = false;                 // PT_STATS=1: count phases and active lanes (slower)
+    int stats = 0;                      // PT_STATS=1: phase/lane counters + box-test cross-check; 2: counters + per-section clocks
     double workspace_gb = 16.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
@@ -458,7 +458,7 @@ struct Tunables {
         if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_LEAF_THRESHOLD")) leaf_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_KERNEL")) force_pixels_kernel = std::strcmp(v, "pixels") == 0;
-        if (const char* v = std::getenv("PT_STATS")) stats = std::atoi(v) != 0;
+        if (const char* v = std::getenv("PT_STATS")) stats = std::min(2, std::max(0, std::atoi(v)));
         if (const char* v = std::getenv("PT_WORKSPACE_GB")) workspace_gb = std::atof(v);
         if (const char* v = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::atoi(v);
     }
@@ -471,7 +471,7 @@ int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_dev
     return PT_OK;
 }
 
-template <bool STATS, bool NODE32>
+template <int STATS, bool NODE32>
 int launch_trace_paths(unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp, const WorkParams& wp,
                        double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
     auto kernel = trace_paths_kernel<STATS, NODE32>;
@@ -485,14 +485,18 @@ int launch_trace_paths(unsigned blocks, hipStream_t stream, const DeviceScene& d
 }
 
 // Dispatch over the two compile-time switches; with `blocks_per_cu` set it only queries occupancy.
-int trace_paths(bool stats_build, bool node32, unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
+int trace_paths(int stats_build, bool node32, unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
                 const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
-    if (stats_build) {
-        return node32 ? launch_trace_paths<true, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                      : launch_trace_paths<true, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    if (stats_build == 1) {
+        return node32 ? launch_trace_paths<1, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                      : launch_trace_paths<1, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
     }
-    return node32 ? launch_trace_paths<false, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                  : launch_trace_paths<false, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    if (stats_build == 2) {
+        return node32 ? launch_trace_paths<2, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                      : launch_trace_paths<2, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    }
+    return node32 ? launch_trace_paths<0, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                  : launch_trace_paths<0, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
 }
 
 // Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
@@ -513,7 +517,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     }
     if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
     const bool node32 = scene->dev.tri_pairs32 != nullptr && !t.force_f64_nodes;
-    const int variant = (t.stats ? 2 : 0) + (node32 ? 1 : 0);
+    const int variant = 2 * t.stats + (node32 ? 1 : 0);
     if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
@@ -553,7 +557,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
                            fp, wp, static_cast<const double*>(scene->rgb.p), accum_device);
         HIP_TRY(hipGetLastError());
     }
-    scene->has_stats = t.stats;
+    scene->has_stats = t.stats != 0;
     return PT_OK;
 }
 

@@ -44,11 +44,13 @@ struct WorkParams {
 // (j / 64) of the chunk's sample group at pixel (j % 64) of the chunk's tile.
 PT_DEV long long rgb_index(long long chunk, int channel, int j) { return (chunk * 3 + channel) * CHUNK_PATHS + j; }
 
-enum LaneState { ST_NEED = 0, ST_NODE = 1, ST_LEAF = 2, ST_SHADE = 3, ST_NEWRAY = 4 };
+// ST_NODE and ST_POP are the two states of the inner-node phase: `st >= ST_NODE` selects both
+enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4, ST_POP = 5 };
 
 struct WaveStats {   // wave-uniform counters of a profiling build
     unsigned long long node_phases, node_lanes, leaf_phases, leaf_lanes, shade_phases, shade_lanes, loops, paths;
     unsigned long long unsafe_skips;   // f32 test skipped a box the exact test accepts: must stay 0
+    unsigned long long t_node, t_leaf, t_shade, t_refill, t_setup, t_total;   // shader-clock ticks spent per section
 };
 
 struct WaveShared {
@@ -57,10 +59,12 @@ struct WaveShared {
     TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];
 };
 
+// STATS: 0 = none; 1 = phase/lane counters and the f32-versus-f64 box-test cross-check; 2 = the
+// counters and shader-clock time per section (no cross-check, so the times are the product's).
 // NODE32: inner nodes are the 64-byte single-precision pairs (conservative test, exact test
 // repeated at the leaf); otherwise the 128-byte double-precision pairs, whose test is the
 // reference's own.
-template <bool STATS, bool NODE32>
+template <int STATS, bool NODE32>
 __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene s, FrameParams f, WorkParams w,
                                                                     double* __restrict__ rgb,
                                                                     unsigned int* __restrict__ next_chunk,
@@ -80,7 +84,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
     int bands_tried = 0;
     // HW_REG_XCC_ID (hardware register 20, bits 3:0): which of the 8 XCDs this wave runs on
     const int home_band = (w.bands > 1) ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % w.bands : 0;
-    WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = (STATS == 2) ? clock64() : 0;
+    long long t0 = 0;
 
     // per-lane path state
     int st = ST_NEED;
@@ -94,20 +100,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
     D3 inv{0, 0, 1}, att{1.0f, 1.0f, 1.0f};
     Ray32 r32{0, 0, 0, 0, 0, 0, 1, 1, 1};
 
-    // Leaves the current node: next pending subtree that can still matter, or the end of the search.
-    auto pop = [&]() {
-        for (;;) {
-            if (sp == 0) { st = ST_SHADE; return; }
-            --sp;
-            cur = stack_ref[sp * BLOCK_THREADS];
-            if (NODE32 && stack_low[sp * BLOCK_THREADS] > cut32) continue;   // fell behind the best hit since it was pushed
-            st = (cur < 0) ? ST_LEAF : ST_NODE;
-            return;
-        }
+    // Leaves the current node: takes the pending subtree on top of the stack.  One attempt, no loop: an
+    // entry that fell behind the best hit since it was pushed leaves the lane in ST_POP, and the lane
+    // tries again in the next inner-node phase, so the other lanes never wait for a lane that unwinds.
+    auto pop_once = [&]() {
+        const int top = max(sp - 1, 0);
+        const int pending = stack_ref[top * BLOCK_THREADS];
+        bool live = true;
+        if (NODE32) live = !(stack_low[top * BLOCK_THREADS] > cut32);
+        st = (sp == 0) ? ST_SHADE : (live ? (pending < 0 ? ST_LEAF : ST_NODE) : ST_POP);
+        sp = top;
+        cur = pending;
     };
 
     for (;;) {
-        const unsigned long long m_node = __ballot(st == ST_NODE);
+        const unsigned long long m_node = __ballot(st >= ST_NODE);
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
         const unsigned long long m_ready = __ballot(st == ST_SHADE || (st == ST_NEED && work_left));
         const int n_ready = __popcll(m_ready);
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
         if ((m_node | m_leaf) == 0ull || n_ready >= w.shade_threshold) {
             if (n_ready == 0) break;      // nothing in flight, nothing to shade, no work left
             if (STATS) { ++ws.shade_phases; ws.shade_lanes += n_ready; }
+            if (STATS == 2) t0 = clock64();
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                     st = ST_NEWRAY;
                 }
             }
+            if (STATS == 2) { const long long t1 = clock64(); ws.t_shade += t1 - t0; t0 = t1; }
             // ---------------- hand new paths to idle lanes
             for (;;) {
                 const unsigned long long m_need = __ballot(st == ST_NEED);
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                 if (STATS) ws.paths += taken;
                 chunk_next += taken;
             }
+            if (STATS == 2) { const long long t1 = clock64(); ws.t_refill += t1 - t0; t0 = t1; }
             // ---------------- start the search of every new ray (src/path_tracing.cpp:177-178)
             if (st == ST_NEWRAY) {
                 inv = D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
@@ -232,9 +242,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                     }
                 }
             }
+            if (STATS == 2) ws.t_setup += clock64() - t0;
         } else if (m_node == 0ull || __popcll(m_leaf) >= w.leaf_threshold) {
             // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
             if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(m_leaf); }
+            if (STATS == 2) t0 = clock64();
             if (st == ST_LEAF) {
                 const int primitive = ~cur;
                 bool enter = true;
@@ -265,17 +277,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                         tie = true;
                     }
                 }
-                pop();
+                pop_once();
             }
+            if (STATS == 2) ws.t_leaf += clock64() - t0;
         } else {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS) { ++ws.node_phases; ws.node_lanes += __popcll(m_node); }
-            if (st == ST_NODE) {
+            if (STATS == 2) t0 = clock64();
+            // Straight-line code: a lane in ST_POP runs the box tests on node 0 and ignores them.
+            if (st >= ST_NODE) {
+                const bool at_node = (st == ST_NODE);
+                const int node = at_node ? cur : 0;
                 int lref, rref;
                 bool go_l, go_r, left_first;
                 float low_l = 0.0f, low_r = 0.0f;
                 if (NODE32) {
-                    const PairNode32* p = s.tri_pairs32 + cur;
+                    const PairNode32* p = s.tri_pairs32 + node;
                     lref = p->left;
                     rref = p->right;
                     float up_l, up_r;
@@ -284,17 +301,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                     go_l = !skip32(low_l, up_l, cut32);
                     go_r = !skip32(low_r, up_r, cut32);
                     left_first = !(low_r < low_l);
-                    if (STATS) {
-                        const PairNode* q = s.tri_tree.pairs + cur;
+                    if (STATS == 1) {
+                        const PairNode* q = s.tri_tree.pairs + node;
                         double lmin, lmax, rmin, rmax;
                         slab_finite(ray.o, inv, q->lbox[0], q->lbox[1], q->lbox[2], q->lbox[3], q->lbox[4], q->lbox[5], lmin, lmax);
                         slab_finite(ray.o, inv, q->rbox[0], q->rbox[1], q->rbox[2], q->rbox[3], q->rbox[4], q->rbox[5], rmin, rmax);
                         const bool exact_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
                         const bool exact_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
-                        ws.unsafe_skips += __popcll(__ballot((exact_l && !go_l) || (exact_r && !go_r)));
+                        ws.unsafe_skips += __popcll(__ballot(at_node && ((exact_l && !go_l) || (exact_r && !go_r))));
                     }
                 } else {
-                    const PairNode* p = s.tri_tree.pairs + cur;
+                    const PairNode* p = s.tri_tree.pairs + node;
                     lref = p->left;
                     rref = p->right;
                     double lmin, lmax, rmin, rmax;
@@ -304,22 +321,35 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                     go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
                     left_first = !(rmin < lmin);
                 }
-                if (go_l && go_r) {
-                    stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
-                    if (NODE32) stack_low[sp * BLOCK_THREADS] = left_first ? low_r : low_l;
-                    ++sp;
-                    cur = left_first ? lref : rref;
-                    st = (cur < 0) ? ST_LEAF : ST_NODE;
-                } else if (go_l || go_r) {
-                    cur = go_l ? lref : rref;
-                    st = (cur < 0) ? ST_LEAF : ST_NODE;
-                } else {
-                    pop();
-                }
+                go_l = go_l && at_node;
+                go_r = go_r && at_node;
+                const bool both = go_l && go_r;
+                const int near = (both ? left_first : go_l) ? lref : rref;
+                // the far child goes to the slot above the top whether or not it is kept: an inner node
+                // has at most WF_STACK_DEPTH - 1 pending ancestors, so the slot exists
+                stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
+                if (NODE32) stack_low[sp * BLOCK_THREADS] = left_first ? low_r : low_l;
+                sp += both ? 1 : 0;
+                // lanes with nowhere to go take the top of the stack (pop_once, as selects)
+                const bool stuck = !(go_l || go_r);
+                const int top = max(sp - 1, 0);
+                const int pending = stack_ref[top * BLOCK_THREADS];
+                bool live = true;
+                if (NODE32) live = !(stack_low[top * BLOCK_THREADS] > cut32);
+                const int next = stuck ? pending : near;
+                const int walk = (next < 0) ? ST_LEAF : ST_NODE;
+                st = stuck ? ((sp == 0) ? ST_SHADE : (live ? walk : ST_POP)) : walk;
+                sp = stuck ? top : sp;
+                cur = next;
             }
+            if (STATS == 2) ws.t_node += clock64() - t0;
         }
     }
     if (STATS && lane == 0) {
+        if (STATS == 2) atomicAdd(stats + 15, 1ull);   // waves
+        atomicAdd(stats + 9, ws.t_node); atomicAdd(stats + 10, ws.t_leaf); atomicAdd(stats + 11, ws.t_shade);
+        atomicAdd(stats + 12, ws.t_refill); atomicAdd(stats + 13, ws.t_setup);
+        atomicAdd(stats + 14, (unsigned long long)(clock64() - t_begin));
         atomicAdd(stats + 0, ws.node_phases); atomicAdd(stats + 1, ws.node_lanes);
         atomicAdd(stats + 2, ws.leaf_phases); atomicAdd(stats + 3, ws.leaf_lanes);
         atomicAdd(stats + 4, ws.shade_phases); atomicAdd(stats + 5, ws.shade_lanes);

@@ -11,7 +11,8 @@ bounces = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 if name.startswith("grid"):
     host = api.HostScene(abi.PT_SCENE_CHESS_GRID, api.MODELS_DIR, int(name[4:]))
 else:
-    host = api.HostScene({"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED}[name], api.MODELS_DIR)
+    host = api.HostScene({"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
+                          "spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}[name], api.MODELS_DIR)
 import time
 t0 = time.time()
 dev = api.DeviceScene.from_host(host)
@@ -31,6 +32,8 @@ try:
     for k in ("node", "leaf", "shade"):
         out[k + "_lanes_per_phase"] = st[k + "_lanes"] / max(1, st[k + "_phases"])
     out["per_path"] = {k: st[k + "_lanes"] / st["paths"] for k in ("node", "leaf", "shade")}
+    if st.get("t_total"):
+        out["clock_share"] = {k: st["t_" + k] / st["t_total"] for k in ("node", "leaf", "shade", "refill", "setup")}
 except Exception as e:
     out["stats_error"] = str(e)
 print(json.dumps(out))
