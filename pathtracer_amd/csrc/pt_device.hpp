@@ -133,9 +133,9 @@ PT_DEV bool hit_triangle(const Ray& ray, const Record* __restrict__ t, double& d
     const D3 ap = sub3(p, a);
     const double alpha = dot3(cross3(ab, ap), n) / nn;
     const double beta = dot3(cross3(ap, ac), n) / nn;
-    const bool inside = (alpha >= 0.0f) && (beta >= 0.0f) && (alpha + beta <= 1.0f);
+    const bool inside = (alpha >= 0.0f) & (beta >= 0.0f) & (alpha + beta <= 1.0f);
     distance = dist;
-    return !parallel && (dist >= 1.0e-6f) && inside;
+    return !parallel & (dist >= 1.0e-6f) & inside;
 }
 
 // intersect(ray, sphere), :59-82, followed by the leaf rule of src/path_tracing.cpp:122-125.

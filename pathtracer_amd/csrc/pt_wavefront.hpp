@@ -106,9 +106,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
     auto pop_once = [&]() {
         const int top = max(sp - 1, 0);
         const int pending = stack_ref[top * BLOCK_THREADS];
-        bool live = true;
-        if (NODE32) live = !(stack_low[top * BLOCK_THREADS] > cut32);
-        st = (sp == 0) ? ST_SHADE : (live ? (pending < 0 ? ST_LEAF : ST_NODE) : ST_POP);
+        const float pending_low = NODE32 ? stack_low[top * BLOCK_THREADS] : 0.0f;
+        const int walk = (pending < 0) ? ST_LEAF : ST_NODE;
+        const int unwound = (NODE32 && pending_low > cut32) ? ST_POP : walk;
+        st = (sp == 0) ? ST_SHADE : unwound;
         sp = top;
         cur = pending;
     };
@@ -247,36 +248,29 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
             // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
             if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(m_leaf); }
             if (STATS == 2) t0 = clock64();
+            // Straight-line code: the whole record is fetched at once and the outcome applied with selects.
             if (st == ST_LEAF) {
                 const int primitive = ~cur;
-                bool enter = true;
                 double d;
                 bool hit;
                 if (NODE32) {
                     const LeafRecord* leaf = s.tri_leaves + primitive;
                     double tmin, tmax;
                     slab_finite(ray.o, inv, leaf->box[0], leaf->box[1], leaf->box[2], leaf->box[3], leaf->box[4], leaf->box[5], tmin, tmax);
-                    enter = !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
-                    hit = false;
-                    if (enter) {
-                        hit = hit_triangle(ray, leaf, d);
-                    }
+                    const bool enter = !(tmax < 0.0f) & !(tmin > tmax) & !(tmin > cut);   // no short cut: one basic block
+                    hit = hit_triangle(ray, leaf, d) & enter;
                 } else {
                     hit = hit_triangle(ray, s.tris + primitive, d);   // the box was tested exactly at the parent
                 }
-                if (hit) {
-                    if (d < best_t) {
-                        best_t = d;
-                        best_i = primitive;
-                        tie = false;
-                        if (d < hs.distance) {
-                            cut = prune_cut(d);
-                            if (NODE32) cut32 = cut32_of(cut);
-                        }
-                    } else if (d == best_t) {
-                        tie = true;
-                    }
-                }
+                const bool better = hit & (d < best_t);
+                const bool equal = hit & (d == best_t);
+                const bool closer = better & (d < hs.distance);
+                const double cut_d = prune_cut(d);
+                tie = (tie & !better) | equal;
+                best_t = better ? d : best_t;
+                best_i = better ? primitive : best_i;
+                cut = closer ? cut_d : cut;
+                if (NODE32) cut32 = closer ? cut32_of(cut_d) : cut32;
                 pop_once();
             }
             if (STATS == 2) ws.t_leaf += clock64() - t0;
