@@ -363,10 +363,10 @@ int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, Pt
     std::vector<PairNode32> pairs32(pairs.size());
     for (size_t i = 0; i < pairs.size(); ++i) {
         for (int k = 0; k < 3; ++k) {
-            pairs32[i].lbox[k] = outward_down(pairs[i].lbox[k]);
-            pairs32[i].lbox[3 + k] = outward_up(pairs[i].lbox[3 + k]);
-            pairs32[i].rbox[k] = outward_down(pairs[i].rbox[k]);
-            pairs32[i].rbox[3 + k] = outward_up(pairs[i].rbox[3 + k]);
+            pairs32[i].plane[k][0] = outward_down(pairs[i].lbox[k]);
+            pairs32[i].plane[3 + k][0] = outward_up(pairs[i].lbox[3 + k]);
+            pairs32[i].plane[k][1] = outward_down(pairs[i].rbox[k]);
+            pairs32[i].plane[3 + k][1] = outward_up(pairs[i].rbox[3 + k]);
         }
         pairs32[i].left = pairs[i].left;
         pairs32[i].right = pairs[i].right;

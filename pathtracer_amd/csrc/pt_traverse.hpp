@@ -42,9 +42,10 @@ struct TreeRef {
 // rounding the f32 slab interval contains the exact one; the three roundings per product
 // (subtract, reciprocal, multiply: 3 * 2^-24 relative) are covered by widening the interval by
 // RHO = 2^-20 relative plus EPS32 absolute (denormal range).
+// The two boxes are interleaved, plane[k] = {left box's k-th bound, right box's} with k = min x, y, z,
+// max x, y, z, so that one packed-f32 instruction works on both children.
 struct PairNode32 {
-    float lbox[6];
-    float rbox[6];
+    float plane[6][2];
     int32_t left, right;
     int32_t pad_[2];
 };
@@ -101,6 +102,31 @@ PT_DEV void slab32(const Ray32& r, float b0, float b1, float b2, float b3, float
     const float tmax = fminf(fmaxf(z0, z1), fminf(fmaxf(y0, y1), fmaxf(x0, x1)));
     lower = fmaf(fabsf(tmin), -RHO32, tmin);
     upper = fmaf(fabsf(tmax), RHO32, tmax);
+}
+// Both boxes of a pair at once on 2-wide vectors (component 0 = left child, 1 = right child).
+typedef float Float2 __attribute__((ext_vector_type(2)));
+PT_DEV Float2 min2(Float2 a, Float2 b) { return Float2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+PT_DEV Float2 max2(Float2 a, Float2 b) { return Float2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+#ifndef PT_PACKED_SLAB
+#define PT_PACKED_SLAB 1
+#endif
+PT_DEV void slab32_pair(const Ray32 r, const PairNode32* __restrict__ p, Float2& lower, Float2& upper) {
+#if !PT_PACKED_SLAB
+    float low_l, up_l, low_r, up_r;
+    slab32(r, p->plane[0][0], p->plane[1][0], p->plane[2][0], p->plane[3][0], p->plane[4][0], p->plane[5][0], low_l, up_l);
+    slab32(r, p->plane[0][1], p->plane[1][1], p->plane[2][1], p->plane[3][1], p->plane[4][1], p->plane[5][1], low_r, up_r);
+    lower = Float2{low_l, low_r};
+    upper = Float2{up_l, up_r};
+    return;
+#endif
+    const Float2* plane = reinterpret_cast<const Float2*>(p->plane);
+    const Float2 x0 = (plane[0] - r.ohx) * r.ix, x1 = (plane[3] - r.olx) * r.ix;
+    const Float2 y0 = (plane[1] - r.ohy) * r.iy, y1 = (plane[4] - r.oly) * r.iy;
+    const Float2 z0 = (plane[2] - r.ohz) * r.iz, z1 = (plane[5] - r.olz) * r.iz;
+    const Float2 tmin = max2(min2(z0, z1), max2(min2(y0, y1), min2(x0, x1)));
+    const Float2 tmax = min2(max2(z0, z1), min2(max2(y0, y1), max2(x0, x1)));
+    lower = Float2{fmaf(fabsf(tmin.x), -RHO32, tmin.x), fmaf(fabsf(tmin.y), -RHO32, tmin.y)};
+    upper = Float2{fmaf(fabsf(tmax.x), RHO32, tmax.x), fmaf(fabsf(tmax.y), RHO32, tmax.y)};
 }
 // May the subtree be skipped?  Never true for a box the exact test accepts within `cut`.
 PT_DEV bool skip32(float lower, float upper, float cut32) {

@@ -26,7 +26,10 @@
 
 namespace ptd {
 
-constexpr int SAMPLES_PER_CHUNK = 16;
+#ifndef PT_SAMPLES_PER_CHUNK
+#define PT_SAMPLES_PER_CHUNK 16
+#endif
+constexpr int SAMPLES_PER_CHUNK = PT_SAMPLES_PER_CHUNK;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
 constexpr int WF_STACK_DEPTH = 24;     // trees up to 25 levels (2^24 leaves in the reference's balanced build)
 
@@ -53,9 +56,17 @@ struct WaveStats {   // wave-uniform counters of a profiling build
     unsigned long long t_node, t_leaf, t_shade, t_refill, t_setup, t_total;   // shader-clock ticks spent per section
 };
 
+// POP_PRUNE keeps, beside each pending subtree, the lower bound of its entry distance, and drops
+// the entry at pop time if the best hit has come closer since.  Without it the entry is visited
+// and its children fail the box test: the same wasted lane-step, but half the LDS per block.
+#ifndef PT_POP_PRUNE
+#define PT_POP_PRUNE 0
+#endif
+constexpr bool POP_PRUNE = PT_POP_PRUNE != 0;
+
 struct WaveShared {
     int stack_ref[WF_STACK_DEPTH * BLOCK_THREADS];      // [level][thread]: pending far children
-    float stack_low[WF_STACK_DEPTH * BLOCK_THREADS];    // lower bound of their entry distance
+    float stack_low[POP_PRUNE ? WF_STACK_DEPTH * BLOCK_THREADS : 1];    // lower bound of their entry distance
     TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];
 };
 
@@ -64,15 +75,18 @@ struct WaveShared {
 // NODE32: inner nodes are the 64-byte single-precision pairs (conservative test, exact test
 // repeated at the leaf); otherwise the 128-byte double-precision pairs, whose test is the
 // reference's own.
+#ifndef PT_WAVES_PER_SIMD
+#define PT_WAVES_PER_SIMD 3
+#endif
 template <int STATS, bool NODE32>
-__global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene s, FrameParams f, WorkParams w,
+__global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_kernel(DeviceScene s, FrameParams f, WorkParams w,
                                                                     double* __restrict__ rgb,
                                                                     unsigned int* __restrict__ next_chunk,
                                                                     unsigned long long* __restrict__ stats) {
     __shared__ WaveShared sh;
     const int lane = threadIdx.x & 63;
     int* const stack_ref = sh.stack_ref + threadIdx.x;
-    float* const stack_low = sh.stack_low + threadIdx.x;
+    float* const stack_low = sh.stack_low + (POP_PRUNE ? threadIdx.x : 0);
     TourFrame* const frames = sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1);
     const TriLeaf tri_leaf{s.tris};
     const SphLeaf sph_leaf{s.spheres};
@@ -106,9 +120,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
     auto pop_once = [&]() {
         const int top = max(sp - 1, 0);
         const int pending = stack_ref[top * BLOCK_THREADS];
-        const float pending_low = NODE32 ? stack_low[top * BLOCK_THREADS] : 0.0f;
+        const float pending_low = (NODE32 && POP_PRUNE) ? stack_low[top * BLOCK_THREADS] : 0.0f;
         const int walk = (pending < 0) ? ST_LEAF : ST_NODE;
-        const int unwound = (NODE32 && pending_low > cut32) ? ST_POP : walk;
+        const int unwound = (NODE32 && POP_PRUNE && pending_low > cut32) ? ST_POP : walk;
         st = (sp == 0) ? ST_SHADE : unwound;
         sp = top;
         cur = pending;
@@ -289,11 +303,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                     const PairNode32* p = s.tri_pairs32 + node;
                     lref = p->left;
                     rref = p->right;
-                    float up_l, up_r;
-                    slab32(r32, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], low_l, up_l);
-                    slab32(r32, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], low_r, up_r);
-                    go_l = !skip32(low_l, up_l, cut32);
-                    go_r = !skip32(low_r, up_r, cut32);
+                    Float2 low, up;
+                    slab32_pair(r32, p, low, up);
+                    low_l = low.x;
+                    low_r = low.y;
+                    go_l = !skip32(low.x, up.x, cut32);
+                    go_r = !skip32(low.y, up.y, cut32);
                     left_first = !(low_r < low_l);
                     if (STATS == 1) {
                         const PairNode* q = s.tri_tree.pairs + node;
@@ -322,14 +337,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void trace_paths_kernel(DeviceScene 
                 // the far child goes to the slot above the top whether or not it is kept: an inner node
                 // has at most WF_STACK_DEPTH - 1 pending ancestors, so the slot exists
                 stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
-                if (NODE32) stack_low[sp * BLOCK_THREADS] = left_first ? low_r : low_l;
+                if (NODE32 && POP_PRUNE) stack_low[sp * BLOCK_THREADS] = left_first ? low_r : low_l;
                 sp += both ? 1 : 0;
                 // lanes with nowhere to go take the top of the stack (pop_once, as selects)
                 const bool stuck = !(go_l || go_r);
                 const int top = max(sp - 1, 0);
                 const int pending = stack_ref[top * BLOCK_THREADS];
                 bool live = true;
-                if (NODE32) live = !(stack_low[top * BLOCK_THREADS] > cut32);
+                if (NODE32 && POP_PRUNE) live = !(stack_low[top * BLOCK_THREADS] > cut32);
                 const int next = stuck ? pending : near;
                 const int walk = (next < 0) ? ST_LEAF : ST_NODE;
                 st = stuck ? ((sp == 0) ? ST_SHADE : (live ? walk : ST_POP)) : walk;

@@ -5,6 +5,8 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pathtracer_amd import api, ctypes_abi as abi
+if os.environ.get("PT_VARIANT"):      # an A/B build made by profiles/build_variant.sh
+    api.LIBRARY_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build_variants", "libpt_%s.so" % os.environ["PT_VARIANT"])
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 name = sys.argv[2] if len(sys.argv) > 2 else "chess32"
 bounces = int(sys.argv[3]) if len(sys.argv) > 3 else 50
@@ -20,12 +22,14 @@ create_seconds = time.time() - t0
 w, h = 1920, 1080
 buf = torch.zeros(4 * w * h, dtype=torch.float64, device="cuda:0")
 fr = host.frame(w, h, sample_count=spp, max_bounces=bounces)
-for i in range(2):
+all_ms = []
+for i in range(int(os.environ.get("ITERATIONS", "2"))):
     buf.zero_()
     dev.render_device(fr, buf.data_ptr())
     torch.cuda.synchronize()
+    all_ms.append(round(dev.last_render_ms(), 2))
 ms = dev.last_render_ms()
-out = {"scene": name, "spp": spp, "max_bounces": bounces, "scene_create_s": create_seconds, "ms": ms, "msamples_per_s": w * h * spp / ms / 1e3}
+out = {"all_ms": all_ms, "scene": name, "spp": spp, "max_bounces": bounces, "scene_create_s": create_seconds, "ms": ms, "msamples_per_s": w * h * spp / ms / 1e3}
 try:
     st = dev.last_render_stats()
     out["stats"] = st
