@@ -283,8 +283,9 @@ D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
 struct PtScene {
     int device = 0;
     DeviceScene dev{};
-    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material, tri_pairs32, tri_leaves;
+    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material, tri_quads, tri_quad_boxes, tri_leaves;
     int tri_height = 0, sph_height = 0;
+    int tri_stack_need = 1;             // slots of the wavefront kernel's stack a search of the 4-wide hierarchy can touch
     DeviceBuffer sph_pairs, sph_ref_nodes, spheres, sph_material, materials;
     hipEvent_t start = nullptr, stop = nullptr;
     hipStream_t last_stream = nullptr;
@@ -351,8 +352,69 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
 float outward_down(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) > x) ? std::nextafterf(f, -INFINITY) : f; }
 float outward_up(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) < x) ? std::nextafterf(f, INFINITY) : f; }
 
+// The binary hierarchy collapsed to four children per node.  A node takes the two children of a
+// pair and then, while a slot is free, replaces its largest inner child by that child's two
+// children.  Numbered in depth-first order; `pending` = stack entries that can be waiting when a
+// node is entered (each ancestor leaves at most its other children behind); `deepest_pending` =
+// the most that can be waiting anywhere in the search.
+struct QuadBuild {
+    std::vector<QuadNode32> nodes;
+    std::vector<QuadBoxes64> exact;
+    int deepest_pending = 0;
+};
+
+double box_half_area(const double* b) {
+    const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+int collapse_to_quads(const std::vector<PairNode>& pairs, int pair, int pending, QuadBuild* out) {
+    int ref[4];
+    const double* box[4];
+    int n = 2;
+    ref[0] = pairs[pair].left;  box[0] = pairs[pair].lbox;
+    ref[1] = pairs[pair].right; box[1] = pairs[pair].rbox;
+    while (n < 4) {
+        int widest = -1;
+        for (int i = 0; i < n; ++i) {
+            if (ref[i] >= 0 && (widest < 0 || box_half_area(box[i]) > box_half_area(box[widest]))) widest = i;
+        }
+        if (widest < 0) break;
+        const PairNode& inner = pairs[ref[widest]];
+        ref[widest] = inner.left;  box[widest] = inner.lbox;
+        ref[n] = inner.right;      box[n] = inner.rbox;
+        ++n;
+    }
+    const int index = static_cast<int>(out->nodes.size());
+    out->nodes.emplace_back();
+    out->exact.emplace_back();
+    out->deepest_pending = std::max(out->deepest_pending, pending + n - 1);   // entries left behind while a child of this node is searched
+    {
+        QuadNode32& q = out->nodes[index];
+        QuadBoxes64& e = out->exact[index];
+        for (int i = 0; i < 4; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                // an empty slot is all NaN: the kernel's entry test is false for NaN bounds
+                q.plane[k][i] = (i < n) ? outward_down(box[i][k]) : std::nanf("");
+                q.plane[3 + k][i] = (i < n) ? outward_up(box[i][3 + k]) : std::nanf("");
+                e.box[i][k] = (i < n) ? box[i][k] : std::nan("");
+                e.box[i][3 + k] = (i < n) ? box[i][3 + k] : std::nan("");
+            }
+            q.child[i] = (i < n) ? ref[i] : 0;
+            q.pad_[i] = 0;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (ref[i] >= 0) {
+            const int child = collapse_to_quads(pairs, ref[i], pending + n - 1, out);
+            out->nodes[index].child[i] = child;      // the vector may have grown: index, not a reference
+        }
+    }
+    return index;
+}
+
 // Single-precision inner nodes (boxes rounded outward) and the leaf records of the wavefront
-// kernel.  Skipped, leaving tri_pairs32 null, when a coordinate is outside the range in which
+// kernel.  Skipped, leaving tri_quads null, when a coordinate is outside the range in which
 // the f32 slab products are guaranteed finite.
 int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, PtScene* scene) {
     const PtAabb& root = d.triangle_bvh[0].aabb;
@@ -360,18 +422,9 @@ int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, Pt
     for (double v : extent) {
         if (!(std::fabs(v) <= MAX_COORD32)) return PT_OK;      // also false for NaN
     }
-    std::vector<PairNode32> pairs32(pairs.size());
-    for (size_t i = 0; i < pairs.size(); ++i) {
-        for (int k = 0; k < 3; ++k) {
-            pairs32[i].plane[k][0] = outward_down(pairs[i].lbox[k]);
-            pairs32[i].plane[3 + k][0] = outward_up(pairs[i].lbox[3 + k]);
-            pairs32[i].plane[k][1] = outward_down(pairs[i].rbox[k]);
-            pairs32[i].plane[3 + k][1] = outward_up(pairs[i].rbox[3 + k]);
-        }
-        pairs32[i].left = pairs[i].left;
-        pairs32[i].right = pairs[i].right;
-        pairs32[i].pad_[0] = pairs32[i].pad_[1] = 0;
-    }
+    QuadBuild quads;
+    if (!pairs.empty()) collapse_to_quads(pairs, 0, 0, &quads);
+    scene->tri_stack_need = quads.deepest_pending + 3;      // a visit writes up to three slots above the pending entries
     std::vector<LeafRecord> leaves(d.triangle_count);
     for (int i = 0; i < d.triangle_count; ++i) {
         using namespace pt;
@@ -389,13 +442,16 @@ int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, Pt
         r.nn = dot(n, n);
         r.pad_ = 0.0;
     }
-    int rc = upload(scene->tri_pairs32, pairs32.data(), pairs32.size() * sizeof(PairNode32));
+    int rc = upload(scene->tri_quads, quads.nodes.data(), quads.nodes.size() * sizeof(QuadNode32));
+    if (rc != PT_OK) return rc;
+    rc = upload(scene->tri_quad_boxes, quads.exact.data(), quads.exact.size() * sizeof(QuadBoxes64));
     if (rc != PT_OK) return rc;
     rc = upload(scene->tri_leaves, leaves.data(), leaves.size() * sizeof(LeafRecord));
     if (rc != PT_OK) return rc;
-    scene->dev.tri_pairs32 = pairs32.empty() && d.triangle_count != 1 ? nullptr : scene->tri_pairs32.as<PairNode32>();
+    scene->dev.tri_quads = scene->tri_quads.as<QuadNode32>();
+    scene->dev.tri_quad_boxes = scene->tri_quad_boxes.as<QuadBoxes64>();
     scene->dev.tri_leaves = scene->tri_leaves.as<LeafRecord>();
-    if (d.triangle_count == 1) scene->dev.tri_pairs32 = reinterpret_cast<const PairNode32*>(scene->dev.tri_leaves);   // no inner node exists; any non-null value enables the path
+    if (d.triangle_count == 1) scene->dev.tri_quads = reinterpret_cast<const QuadNode32*>(scene->dev.tri_leaves);   // no inner node exists; any non-null value enables the path
     return PT_OK;
 }
 
@@ -472,31 +528,31 @@ int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_dev
 }
 
 template <int STATS, bool NODE32>
-int launch_trace_paths(unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp, const WorkParams& wp,
-                       double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
+int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
+                       const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
     auto kernel = trace_paths_kernel<STATS, NODE32>;
     if (blocks_per_cu != nullptr) {
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, BLOCK_THREADS, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, BLOCK_THREADS, stack_bytes));
         return PT_OK;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, dev, fp, wp, rgb, counter, stats);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream, dev, fp, wp, rgb, counter, stats);
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 
 // Dispatch over the two compile-time switches; with `blocks_per_cu` set it only queries occupancy.
-int trace_paths(int stats_build, bool node32, unsigned blocks, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
+int trace_paths(int stats_build, bool node32, unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
                 const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
     if (stats_build == 1) {
-        return node32 ? launch_trace_paths<1, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                      : launch_trace_paths<1, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+        return node32 ? launch_trace_paths<1, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                      : launch_trace_paths<1, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
     }
     if (stats_build == 2) {
-        return node32 ? launch_trace_paths<2, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                      : launch_trace_paths<2, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+        return node32 ? launch_trace_paths<2, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                      : launch_trace_paths<2, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
     }
-    return node32 ? launch_trace_paths<0, true>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                  : launch_trace_paths<0, false>(blocks, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    return node32 ? launch_trace_paths<0, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
+                  : launch_trace_paths<0, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
 }
 
 // Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
@@ -516,7 +572,10 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         scene->rgb_bytes = need;
     }
     if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
-    const bool node32 = scene->dev.tri_pairs32 != nullptr && !t.force_f64_nodes;
+    const bool node32 = scene->dev.tri_quads != nullptr && !t.force_f64_nodes;
+    // per-lane stack slots: the triangle search's need, and the sphere tree's when it is walked in place
+    const int stack_slots = std::max(std::max(node32 ? scene->tri_stack_need : scene->tri_height, scene->sph_height), 1);
+    const size_t stack_bytes = static_cast<size_t>(stack_slots) * BLOCK_THREADS * sizeof(int);
     const int variant = 2 * t.stats + (node32 ? 1 : 0);
     if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
         hipDeviceProp_t prop;
@@ -524,7 +583,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         scene->compute_units = prop.multiProcessorCount;
         scene->occupancy_variant = variant;
         int per_cu = 0;
-        const int rc = trace_paths(t.stats, node32, 0, stream, scene->dev, FrameParams{}, WorkParams{}, nullptr, nullptr, nullptr, &per_cu);
+        const int rc = trace_paths(t.stats, node32, 0, stack_bytes, stream, scene->dev, FrameParams{}, WorkParams{}, nullptr, nullptr, nullptr, &per_cu);
         if (rc != PT_OK) return rc;
         scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
     }
@@ -546,12 +605,13 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.bands = t.xcd_bands ? 8 : 1;
         wp.shade_threshold = t.shade_threshold;
         wp.leaf_threshold = t.leaf_threshold;
+        wp.stack_slots = stack_slots;
         if (wp.chunk_count >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld chunks", wp.chunk_count);
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
         first = false;
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
                                                                           (wp.chunk_count + 3) / 4));
-        const int rc = trace_paths(t.stats, node32, blocks, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats, nullptr);
+        const int rc = trace_paths(t.stats, node32, blocks, stack_bytes, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats, nullptr);
         if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,
                            fp, wp, static_cast<const double*>(scene->rgb.p), accum_device);
@@ -569,7 +629,8 @@ int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hi
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
     const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel &&
-                           scene->tri_height <= WF_STACK_DEPTH + 1 && scene->sph_height <= WF_STACK_DEPTH + 1;
+                           scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS &&
+                           scene->tri_stack_need <= MAX_WF_STACK_SLOTS;
     const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream) : launch_pixels_kernel(scene, frame, accum_device, stream);
     if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->stop, stream));

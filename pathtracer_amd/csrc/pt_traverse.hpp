@@ -42,14 +42,16 @@ struct TreeRef {
 // rounding the f32 slab interval contains the exact one; the three roundings per product
 // (subtract, reciprocal, multiply: 3 * 2^-24 relative) are covered by widening the interval by
 // RHO = 2^-20 relative plus EPS32 absolute (denormal range).
-// The two boxes are interleaved, plane[k] = {left box's k-th bound, right box's} with k = min x, y, z,
-// max x, y, z, so that one packed-f32 instruction works on both children.
-struct PairNode32 {
-    float plane[6][2];
-    int32_t left, right;
-    int32_t pad_[2];
+// Four children per node: a node of the binary hierarchy with its children (and, while slots are
+// free, the largest grandchildren) pulled up.  plane[k] holds the k-th bound (min x, y, z, max x, y,
+// z) of the four child boxes side by side; an empty slot has min > max and is never entered.
+struct QuadNode32 {
+    float plane[6][4];
+    int32_t child[4];      // >= 0: quad index, < 0: ~primitive
+    int32_t pad_[4];
 };
-static_assert(sizeof(PairNode32) == 64, "PairNode32 is half a 128-byte line");
+static_assert(sizeof(QuadNode32) == 128, "QuadNode32 is one 128-byte line");
+struct QuadBoxes64 { double box[4][6]; };   // the exact child boxes, read only by the cross-checking build
 
 // Everything a leaf visit needs: the leaf's exact box, then the ray-independent part of the
 // triangle test (same fields as TriRecord without the unit normal).  160 B = ten 16-byte loads.
@@ -103,41 +105,49 @@ PT_DEV void slab32(const Ray32& r, float b0, float b1, float b2, float b3, float
     lower = fmaf(fabsf(tmin), -RHO32, tmin);
     upper = fmaf(fabsf(tmax), RHO32, tmax);
 }
-// Both boxes of a pair at once on 2-wide vectors (component 0 = left child, 1 = right child).
-typedef float Float2 __attribute__((ext_vector_type(2)));
-PT_DEV Float2 min2(Float2 a, Float2 b) { return Float2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
-PT_DEV Float2 max2(Float2 a, Float2 b) { return Float2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-#ifndef PT_PACKED_SLAB
-#define PT_PACKED_SLAB 1
-#endif
-PT_DEV void slab32_pair(const Ray32 r, const PairNode32* __restrict__ p, Float2& lower, Float2& upper) {
-#if !PT_PACKED_SLAB
-    float low_l, up_l, low_r, up_r;
-    slab32(r, p->plane[0][0], p->plane[1][0], p->plane[2][0], p->plane[3][0], p->plane[4][0], p->plane[5][0], low_l, up_l);
-    slab32(r, p->plane[0][1], p->plane[1][1], p->plane[2][1], p->plane[3][1], p->plane[4][1], p->plane[5][1], low_r, up_r);
-    lower = Float2{low_l, low_r};
-    upper = Float2{up_l, up_r};
-    return;
-#endif
-    const Float2* plane = reinterpret_cast<const Float2*>(p->plane);
-    const Float2 x0 = (plane[0] - r.ohx) * r.ix, x1 = (plane[3] - r.olx) * r.ix;
-    const Float2 y0 = (plane[1] - r.ohy) * r.iy, y1 = (plane[4] - r.oly) * r.iy;
-    const Float2 z0 = (plane[2] - r.ohz) * r.iz, z1 = (plane[5] - r.olz) * r.iz;
-    const Float2 tmin = max2(min2(z0, z1), max2(min2(y0, y1), min2(x0, x1)));
-    const Float2 tmax = min2(max2(z0, z1), min2(max2(y0, y1), max2(x0, x1)));
-    lower = Float2{fmaf(fabsf(tmin.x), -RHO32, tmin.x), fmaf(fabsf(tmin.y), -RHO32, tmin.y)};
-    upper = Float2{fmaf(fabsf(tmax.x), RHO32, tmax.x), fmaf(fabsf(tmax.y), RHO32, tmax.y)};
+// All four child boxes at once on 4-wide vectors.
+typedef float Float4 __attribute__((ext_vector_type(4)));
+PT_DEV Float4 min4(Float4 a, Float4 b) { return Float4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)}; }
+PT_DEV Float4 max4(Float4 a, Float4 b) { return Float4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ q, Float4& lower, Float4& upper) {
+    const Float4* plane = reinterpret_cast<const Float4*>(q->plane);
+    const Float4 x0 = (plane[0] - r.ohx) * r.ix, x1 = (plane[3] - r.olx) * r.ix;
+    const Float4 y0 = (plane[1] - r.ohy) * r.iy, y1 = (plane[4] - r.oly) * r.iy;
+    const Float4 z0 = (plane[2] - r.ohz) * r.iz, z1 = (plane[5] - r.olz) * r.iz;
+    const Float4 tmin = max4(min4(z0, z1), max4(min4(y0, y1), min4(x0, x1)));
+    const Float4 tmax = min4(max4(z0, z1), min4(max4(y0, y1), max4(x0, x1)));
+    lower = Float4{fmaf(fabsf(tmin.x), -RHO32, tmin.x), fmaf(fabsf(tmin.y), -RHO32, tmin.y),
+                   fmaf(fabsf(tmin.z), -RHO32, tmin.z), fmaf(fabsf(tmin.w), -RHO32, tmin.w)};
+    upper = Float4{fmaf(fabsf(tmax.x), RHO32, tmax.x), fmaf(fabsf(tmax.y), RHO32, tmax.y),
+                   fmaf(fabsf(tmax.z), RHO32, tmax.z), fmaf(fabsf(tmax.w), RHO32, tmax.w)};
 }
 // May the subtree be skipped?  Never true for a box the exact test accepts within `cut`.
 PT_DEV bool skip32(float lower, float upper, float cut32) {
     return (upper < -EPS32) || (lower - upper > EPS32) || (lower > cut32);
 }
 
+// May the child be entered?  True for every box the exact test accepts within `cut`; false for NaN
+// bounds (empty slots).
+PT_DEV bool enter32(float lower, float upper, float cut32) {
+    return (upper >= -EPS32) & (lower - upper <= EPS32) & (lower <= cut32);
+}
+// Puts the pair with the smaller key first.
+PT_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
+    const bool swap = kb < ka;
+    const float k = swap ? kb : ka;
+    const int r = swap ? rb : ra;
+    kb = swap ? ka : kb;
+    rb = swap ? ra : rb;
+    ka = k;
+    ra = r;
+}
+
 struct DeviceScene {
     TreeRef tri_tree;
     const TriRecord* tris;
     const int32_t* tri_material;
-    const PairNode32* tri_pairs32;   // same numbering as tri_tree.pairs; null if the scene is out of f32 range
+    const QuadNode32* tri_quads;     // 4-wide single-precision hierarchy; null if the scene is out of f32 range
+    const QuadBoxes64* tri_quad_boxes;
     const LeafRecord* tri_leaves;
     TreeRef sph_tree;
     const double* spheres;        // 4 doubles each

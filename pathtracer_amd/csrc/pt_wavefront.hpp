@@ -31,7 +31,8 @@ namespace ptd {
 #endif
 constexpr int SAMPLES_PER_CHUNK = PT_SAMPLES_PER_CHUNK;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
-constexpr int WF_STACK_DEPTH = 24;     // trees up to 25 levels (2^24 leaves in the reference's balanced build)
+constexpr int WF_STACK_DEPTH = 24;     // the rebuilt hierarchy is kept to 25 levels
+constexpr int MAX_WF_STACK_SLOTS = 48; // per-lane stack slots one block may be given (48 KB of LDS)
 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
@@ -41,14 +42,14 @@ struct WorkParams {
     int bands;                   // 8: one chunk counter per XCD, tile row r belongs to band r % 8; 1: a single counter
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
+    int stack_slots;             // per-lane stack slots the launch provides in LDS
 };
 
 // rgb layout: [chunk][channel r,g,b][CHUNK_PATHS] doubles; path j of a chunk is sample
 // (j / 64) of the chunk's sample group at pixel (j % 64) of the chunk's tile.
 PT_DEV long long rgb_index(long long chunk, int channel, int j) { return (chunk * 3 + channel) * CHUNK_PATHS + j; }
 
-// ST_NODE and ST_POP are the two states of the inner-node phase: `st >= ST_NODE` selects both
-enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4, ST_POP = 5 };
+enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4 };
 
 struct WaveStats {   // wave-uniform counters of a profiling build
     unsigned long long node_phases, node_lanes, leaf_phases, leaf_lanes, shade_phases, shade_lanes, loops, paths;
@@ -56,25 +57,17 @@ struct WaveStats {   // wave-uniform counters of a profiling build
     unsigned long long t_node, t_leaf, t_shade, t_refill, t_setup, t_total;   // shader-clock ticks spent per section
 };
 
-// POP_PRUNE keeps, beside each pending subtree, the lower bound of its entry distance, and drops
-// the entry at pop time if the best hit has come closer since.  Without it the entry is visited
-// and its children fail the box test: the same wasted lane-step, but half the LDS per block.
-#ifndef PT_POP_PRUNE
-#define PT_POP_PRUNE 0
-#endif
-constexpr bool POP_PRUNE = PT_POP_PRUNE != 0;
-
+// LDS: the tournament frames of the exhaustive fallback (static) and the lanes' stacks of pending
+// subtrees, [slot][thread], sized at launch to what the scene's hierarchy can need (dynamic).
 struct WaveShared {
-    int stack_ref[WF_STACK_DEPTH * BLOCK_THREADS];      // [level][thread]: pending far children
-    float stack_low[POP_PRUNE ? WF_STACK_DEPTH * BLOCK_THREADS : 1];    // lower bound of their entry distance
     TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];
 };
 
 // STATS: 0 = none; 1 = phase/lane counters and the f32-versus-f64 box-test cross-check; 2 = the
 // counters and shader-clock time per section (no cross-check, so the times are the product's).
-// NODE32: inner nodes are the 64-byte single-precision pairs (conservative test, exact test
-// repeated at the leaf); otherwise the 128-byte double-precision pairs, whose test is the
-// reference's own.
+// NODE32: inner nodes are the 128-byte single-precision nodes with four children (conservative
+// test, exact test repeated at the leaf); otherwise the 128-byte double-precision pairs, whose
+// test is the reference's own.
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
@@ -84,9 +77,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                                                                     unsigned int* __restrict__ next_chunk,
                                                                     unsigned long long* __restrict__ stats) {
     __shared__ WaveShared sh;
+    extern __shared__ int lane_stacks[];
     const int lane = threadIdx.x & 63;
-    int* const stack_ref = sh.stack_ref + threadIdx.x;
-    float* const stack_low = sh.stack_low + (POP_PRUNE ? threadIdx.x : 0);
+    int* const stack_ref = lane_stacks + threadIdx.x;
     TourFrame* const frames = sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1);
     const TriLeaf tri_leaf{s.tris};
     const SphLeaf sph_leaf{s.spheres};
@@ -114,22 +107,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     D3 inv{0, 0, 1}, att{1.0f, 1.0f, 1.0f};
     Ray32 r32{0, 0, 0, 0, 0, 0, 1, 1, 1};
 
-    // Leaves the current node: takes the pending subtree on top of the stack.  One attempt, no loop: an
-    // entry that fell behind the best hit since it was pushed leaves the lane in ST_POP, and the lane
-    // tries again in the next inner-node phase, so the other lanes never wait for a lane that unwinds.
+    // Leaves the current node: takes the pending subtree on top of the stack, or ends the search.
     auto pop_once = [&]() {
         const int top = max(sp - 1, 0);
         const int pending = stack_ref[top * BLOCK_THREADS];
-        const float pending_low = (NODE32 && POP_PRUNE) ? stack_low[top * BLOCK_THREADS] : 0.0f;
-        const int walk = (pending < 0) ? ST_LEAF : ST_NODE;
-        const int unwound = (NODE32 && POP_PRUNE && pending_low > cut32) ? ST_POP : walk;
-        st = (sp == 0) ? ST_SHADE : unwound;
+        st = (sp == 0) ? ST_SHADE : ((pending < 0) ? ST_LEAF : ST_NODE);
         sp = top;
         cur = pending;
     };
 
     for (;;) {
-        const unsigned long long m_node = __ballot(st >= ST_NODE);
+        const unsigned long long m_node = __ballot(st == ST_NODE);
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
         const unsigned long long m_ready = __ballot(st == ST_SHADE || (st == ST_NEED && work_left));
         const int n_ready = __popcll(m_ready);
@@ -252,6 +240,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                             if (NODE32) {
                                 r32 = make_ray32(ray, inv);
                                 cut32 = cut32_of(cut);
+                                if (cur >= 0) cur = 0;       // the 4-wide hierarchy has its own numbering; its root is node 0
                             }
                         }
                     }
@@ -292,64 +281,77 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS) { ++ws.node_phases; ws.node_lanes += __popcll(m_node); }
             if (STATS == 2) t0 = clock64();
-            // Straight-line code: a lane in ST_POP runs the box tests on node 0 and ignores them.
-            if (st >= ST_NODE) {
-                const bool at_node = (st == ST_NODE);
-                const int node = at_node ? cur : 0;
-                int lref, rref;
-                bool go_l, go_r, left_first;
-                float low_l = 0.0f, low_r = 0.0f;
+            // Straight-line code: far children are written above the top of the stack whether or not they
+            // are kept (the launch sizes the stack for it), and every decision is a select.
+            if (st == ST_NODE) {
                 if (NODE32) {
-                    const PairNode32* p = s.tri_pairs32 + node;
-                    lref = p->left;
-                    rref = p->right;
-                    Float2 low, up;
-                    slab32_pair(r32, p, low, up);
-                    low_l = low.x;
-                    low_r = low.y;
-                    go_l = !skip32(low.x, up.x, cut32);
-                    go_r = !skip32(low.y, up.y, cut32);
-                    left_first = !(low_r < low_l);
+                    const QuadNode32* q = s.tri_quads + cur;
+                    const int c0 = q->child[0], c1 = q->child[1], c2 = q->child[2], c3 = q->child[3];
+                    Float4 low, up;
+                    slab32_quad(r32, q, low, up);
+                    // an empty slot holds NaN planes: every comparison below is false for it
+                    const bool go0 = enter32(low.x, up.x, cut32), go1 = enter32(low.y, up.y, cut32);
+                    const bool go2 = enter32(low.z, up.z, cut32), go3 = enter32(low.w, up.w, cut32);
                     if (STATS == 1) {
-                        const PairNode* q = s.tri_tree.pairs + node;
-                        double lmin, lmax, rmin, rmax;
-                        slab_finite(ray.o, inv, q->lbox[0], q->lbox[1], q->lbox[2], q->lbox[3], q->lbox[4], q->lbox[5], lmin, lmax);
-                        slab_finite(ray.o, inv, q->rbox[0], q->rbox[1], q->rbox[2], q->rbox[3], q->rbox[4], q->rbox[5], rmin, rmax);
-                        const bool exact_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
-                        const bool exact_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
-                        ws.unsafe_skips += __popcll(__ballot(at_node && ((exact_l && !go_l) || (exact_r && !go_r))));
+                        const QuadBoxes64* e = s.tri_quad_boxes + cur;
+                        const bool go[4] = {go0, go1, go2, go3};
+                        bool unsafe = false;
+                        for (int i = 0; i < 4; ++i) {
+                            double tmin, tmax;
+                            slab_finite(ray.o, inv, e->box[i][0], e->box[i][1], e->box[i][2], e->box[i][3], e->box[i][4], e->box[i][5], tmin, tmax);
+                            const bool exact = (q->child[i] != 0) && !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
+                            unsafe = unsafe || (exact && !go[i]);
+                        }
+                        ws.unsafe_skips += __popcll(__ballot(unsafe));
                     }
+                    // children in order of entry distance, skipped ones last
+                    const float far = __builtin_inff();
+                    float k0 = go0 ? low.x : far, k1 = go1 ? low.y : far, k2 = go2 ? low.z : far, k3 = go3 ? low.w : far;
+                    int r0 = c0, r1 = c1, r2 = c2, r3 = c3;
+                    order2(k0, r0, k1, r1);
+                    order2(k2, r2, k3, r3);
+                    order2(k0, r0, k2, r2);
+                    order2(k1, r1, k3, r3);
+                    order2(k1, r1, k2, r2);
+                    const int count = (go0 ? 1 : 0) + (go1 ? 1 : 0) + (go2 ? 1 : 0) + (go3 ? 1 : 0);
+                    // kept child i (1 <= i < count) goes to slot sp + count-1-i, the nearest of them on top; the
+                    // others land above the new top and are never read
+                    const int keep = max(count - 1, 0);
+                    stack_ref[(sp + ((1 < count) ? count - 2 : 0)) * BLOCK_THREADS] = r1;
+                    stack_ref[(sp + ((2 < count) ? count - 3 : 1)) * BLOCK_THREADS] = r2;
+                    stack_ref[(sp + ((3 < count) ? 0 : 2)) * BLOCK_THREADS] = r3;
+                    sp += keep;
+                    const bool stuck = (count == 0);
+                    const int top = max(sp - 1, 0);
+                    const int pending = stack_ref[top * BLOCK_THREADS];
+                    const int next = stuck ? pending : r0;
+                    // sp + 3 <= stack_slots holds for every node of a hierarchy the host has measured; the
+                    // test keeps a corrupted node from walking a lane out of its stack
+                    const bool done = (stuck && sp == 0) || (sp + 3 > w.stack_slots);
+                    st = done ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
+                    sp = stuck ? top : sp;
+                    cur = next;
                 } else {
-                    const PairNode* p = s.tri_tree.pairs + node;
-                    lref = p->left;
-                    rref = p->right;
+                    const PairNode* p = s.tri_tree.pairs + cur;
+                    const int lref = p->left, rref = p->right;
                     double lmin, lmax, rmin, rmax;
                     slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
                     slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
-                    go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
-                    go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
-                    left_first = !(rmin < lmin);
+                    const bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
+                    const bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+                    const bool left_first = !(rmin < lmin);
+                    const bool both = go_l && go_r;
+                    const int near = (both ? left_first : go_l) ? lref : rref;
+                    stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
+                    sp += both ? 1 : 0;
+                    const bool stuck = !(go_l || go_r);
+                    const int top = max(sp - 1, 0);
+                    const int pending = stack_ref[top * BLOCK_THREADS];
+                    const int next = stuck ? pending : near;
+                    st = (stuck && sp == 0) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
+                    sp = stuck ? top : sp;
+                    cur = next;
                 }
-                go_l = go_l && at_node;
-                go_r = go_r && at_node;
-                const bool both = go_l && go_r;
-                const int near = (both ? left_first : go_l) ? lref : rref;
-                // the far child goes to the slot above the top whether or not it is kept: an inner node
-                // has at most WF_STACK_DEPTH - 1 pending ancestors, so the slot exists
-                stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
-                if (NODE32 && POP_PRUNE) stack_low[sp * BLOCK_THREADS] = left_first ? low_r : low_l;
-                sp += both ? 1 : 0;
-                // lanes with nowhere to go take the top of the stack (pop_once, as selects)
-                const bool stuck = !(go_l || go_r);
-                const int top = max(sp - 1, 0);
-                const int pending = stack_ref[top * BLOCK_THREADS];
-                bool live = true;
-                if (NODE32 && POP_PRUNE) live = !(stack_low[top * BLOCK_THREADS] > cut32);
-                const int next = stuck ? pending : near;
-                const int walk = (next < 0) ? ST_LEAF : ST_NODE;
-                st = stuck ? ((sp == 0) ? ST_SHADE : (live ? walk : ST_POP)) : walk;
-                sp = stuck ? top : sp;
-                cur = next;
             }
             if (STATS == 2) ws.t_node += clock64() - t0;
         }
