@@ -425,6 +425,10 @@ int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, Pt
     QuadBuild quads;
     if (!pairs.empty()) collapse_to_quads(pairs, 0, 0, &quads);
     scene->tri_stack_need = quads.deepest_pending + 3;      // a visit writes up to three slots above the pending entries
+    if (std::getenv("PT_VERBOSE") != nullptr) {
+        std::fprintf(stderr, "pathtracer_amd: %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", pairs.size(), quads.nodes.size(),
+                     scene->tri_stack_need);
+    }
     std::vector<LeafRecord> leaves(d.triangle_count);
     for (int i = 0; i < d.triangle_count; ++i) {
         using namespace pt;
@@ -506,11 +510,13 @@ struct Tunables {
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
     int shade_threshold = 28;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
     int leaf_threshold = 24;
+    int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
     bool xcd_bands = false;             // PT_XCD=1: one chunk counter per XCD (tile rows dealt to the XCDs) instead of one for the chip
     Tunables() {
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
         if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
         if (const char* v = std::getenv("PT_XCD")) xcd_bands = std::atoi(v) != 0;
+        if (const char* v = std::getenv("PT_STACK_SLOTS")) stack_slots = std::atoi(v);
         if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_LEAF_THRESHOLD")) leaf_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_KERNEL")) force_pixels_kernel = std::strcmp(v, "pixels") == 0;
@@ -574,9 +580,13 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
     const bool node32 = scene->dev.tri_quads != nullptr && !t.force_f64_nodes;
     // per-lane stack slots: the triangle search's need, and the sphere tree's when it is walked in place
-    const int stack_slots = std::max(std::max(node32 ? scene->tri_stack_need : scene->tri_height, scene->sph_height), 1);
+    // (a lane of the 4-wide search that would outgrow its slots falls back to the exhaustive traversal, so
+    // any number >= 3 is correct there; the binary search and the sphere tree need their full height)
+    const int quad_slots = std::max(3, t.stack_slots > 0 ? std::min(t.stack_slots, scene->tri_stack_need) : scene->tri_stack_need);
+    const int stack_slots = std::min(std::max(std::max(node32 ? quad_slots : scene->tri_height, scene->sph_height), 4),
+                                     static_cast<int>(MAX_WF_STACK_SLOTS));
     const size_t stack_bytes = static_cast<size_t>(stack_slots) * BLOCK_THREADS * sizeof(int);
-    const int variant = 2 * t.stats + (node32 ? 1 : 0);
+    const int variant = 4 * stack_slots + 2 * (t.stats & 1) + (node32 ? 1 : 0) + 1024 * (t.stats >> 1);
     if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
@@ -629,8 +639,7 @@ int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hi
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
     const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel &&
-                           scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS &&
-                           scene->tri_stack_need <= MAX_WF_STACK_SLOTS;
+                           scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS;
     const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream) : launch_pixels_kernel(scene, frame, accum_device, stream);
     if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->stop, stream));

@@ -32,7 +32,7 @@ namespace ptd {
 constexpr int SAMPLES_PER_CHUNK = PT_SAMPLES_PER_CHUNK;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
 constexpr int WF_STACK_DEPTH = 24;     // the rebuilt hierarchy is kept to 25 levels
-constexpr int MAX_WF_STACK_SLOTS = 48; // per-lane stack slots one block may be given (48 KB of LDS)
+constexpr int MAX_WF_STACK_SLOTS = 36; // per-lane stack slots a block is given at most (1 KB of LDS each): three blocks per CU still fit
 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
@@ -61,6 +61,7 @@ struct WaveStats {   // wave-uniform counters of a profiling build
 // subtrees, [slot][thread], sized at launch to what the scene's hierarchy can need (dynamic).
 struct WaveShared {
     TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];
+    double pool[BLOCK_THREADS / 64][6][64];     // per wave: the camera rays of the next 64 paths (origin, direction)
 };
 
 // STATS: 0 = none; 1 = phase/lane counters and the f32-versus-f64 box-test cross-check; 2 = the
@@ -81,13 +82,15 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     const int lane = threadIdx.x & 63;
     int* const stack_ref = lane_stacks + threadIdx.x;
     TourFrame* const frames = sh.frames + (threadIdx.x >> 6) * (STACK_DEPTH + 1);
+    double (*const pool)[64] = sh.pool[threadIdx.x >> 6];
     const TriLeaf tri_leaf{s.tris};
     const SphLeaf sph_leaf{s.spheres};
 
     // wave-uniform work state: the chunk being handed out and where its tile and samples lie
     unsigned int chunk = 0;
     int chunk_next = 0, chunk_size = 0, chunk_row0 = 0, chunk_col0 = 0, chunk_sample0 = 0;
-    bool work_left = true;
+    bool work_left = true;          // chunks may remain on the counter
+    int pool_first = 0, pool_taken = 64;   // the pool holds paths pool_first .. +63 of the chunk; entries below pool_taken are gone
     int bands_tried = 0;
     // HW_REG_XCC_ID (hardware register 20, bits 3:0): which of the 8 XCDs this wave runs on
     const int home_band = (w.bands > 1) ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % w.bands : 0;
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     for (;;) {
         const unsigned long long m_node = __ballot(st == ST_NODE);
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
-        const unsigned long long m_ready = __ballot(st == ST_SHADE || (st == ST_NEED && work_left));
+        const bool paths_left = work_left || pool_taken < 64;
+        const unsigned long long m_ready = __ballot(st == ST_SHADE || (st == ST_NEED && paths_left));
         const int n_ready = __popcll(m_ready);
         if (STATS) ++ws.loops;
 
@@ -148,58 +152,70 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             }
             if (STATS == 2) { const long long t1 = clock64(); ws.t_shade += t1 - t0; t0 = t1; }
             // ---------------- hand new paths to idle lanes
+            // Camera rays are made 64 at a time by the whole wave (all lanes busy, whatever their own path is
+            // doing) and parked in LDS; an idle lane then only picks one up.
             for (;;) {
                 const unsigned long long m_need = __ballot(st == ST_NEED);
-                if (m_need == 0ull || !work_left) break;
-                if (chunk_next >= chunk_size) {
-                    // Chunks are dealt per band: tile row r belongs to band r % bands and each band has its own
-                    // counter.  A wave draws from the band of its XCD first, so the waves sharing an L2 work on
-                    // the same rows of tiles; when that band is empty it helps the next one.
-                    const unsigned int per_row = (unsigned int)w.tiles_x * (unsigned int)w.groups_per_tile;
-                    int band = -1;
-                    unsigned int c = 0;
-                    while (bands_tried < w.bands) {
-                        const int b = (home_band + bands_tried) % w.bands;
-                        const unsigned int rows_in_band = (unsigned int)((w.tile_rows - b + w.bands - 1) / w.bands);
-                        unsigned int v = 0;
-                        if (lane == 0) v = atomicAdd(next_chunk + 16 * b, 1u);
-                        v = __builtin_amdgcn_readfirstlane(v);
-                        if (v < rows_in_band * per_row) { band = b; c = v; break; }
-                        ++bands_tried;                       // that band is finished for good
+                if (m_need == 0ull) break;
+                if (pool_taken == 64) {
+                    if (!work_left) break;
+                    if (chunk_next >= chunk_size) {
+                        // Chunks are dealt per band: tile row r belongs to band r % bands and each band has its own
+                        // counter.  A wave draws from the band of its XCD first, so the waves sharing an L2 work on
+                        // the same rows of tiles; when that band is empty it helps the next one.
+                        const unsigned int per_row = (unsigned int)w.tiles_x * (unsigned int)w.groups_per_tile;
+                        int band = -1;
+                        unsigned int c = 0;
+                        while (bands_tried < w.bands) {
+                            const int b = (home_band + bands_tried) % w.bands;
+                            const unsigned int rows_in_band = (unsigned int)((w.tile_rows - b + w.bands - 1) / w.bands);
+                            unsigned int v = 0;
+                            if (lane == 0) v = atomicAdd(next_chunk + 16 * b, 1u);
+                            v = __builtin_amdgcn_readfirstlane(v);
+                            if (v < rows_in_band * per_row) { band = b; c = v; break; }
+                            ++bands_tried;                       // that band is finished for good
+                        }
+                        if (band < 0) { work_left = false; break; }
+                        const unsigned int band_row = c / per_row;
+                        const unsigned int rest = c - band_row * per_row;
+                        const unsigned int tile_col = rest / (unsigned int)w.groups_per_tile;
+                        const int group = (int)(rest - tile_col * (unsigned int)w.groups_per_tile);
+                        const unsigned int tile_row = band_row * (unsigned int)w.bands + (unsigned int)band;
+                        chunk = (tile_row * (unsigned int)w.tiles_x + tile_col) * (unsigned int)w.groups_per_tile + (unsigned int)group;
+                        chunk_next = 0;
+                        chunk_col0 = (int)tile_col * 8;
+                        chunk_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
+                        chunk_sample0 = f.sample_begin + group * SAMPLES_PER_CHUNK;
+                        chunk_size = 64 * min(SAMPLES_PER_CHUNK, f.sample_count - group * SAMPLES_PER_CHUNK);
                     }
-                    if (band < 0) { work_left = false; break; }
-                    const unsigned int band_row = c / per_row;
-                    const unsigned int rest = c - band_row * per_row;
-                    const unsigned int tile_col = rest / (unsigned int)w.groups_per_tile;
-                    const int group = (int)(rest - tile_col * (unsigned int)w.groups_per_tile);
-                    const unsigned int tile_row = band_row * (unsigned int)w.bands + (unsigned int)band;
-                    chunk = (tile_row * (unsigned int)w.tiles_x + tile_col) * (unsigned int)w.groups_per_tile + (unsigned int)group;
-                    chunk_next = 0;
-                    chunk_col0 = (int)tile_col * 8;
-                    chunk_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
-                    chunk_sample0 = f.sample_begin + group * SAMPLES_PER_CHUNK;
-                    chunk_size = 64 * min(SAMPLES_PER_CHUNK, f.sample_count - group * SAMPLES_PER_CHUNK);
+                    // the next sample of the chunk's 64 pixels: lane l makes the ray of pixel l (pixels of a
+                    // partial tile that lie outside the image get a ray too; nobody will pick it up)
+                    const int row = min(chunk_row0 + (lane >> 3), f.height - 1);
+                    const int column = min(chunk_col0 + (lane & 7), f.width - 1);
+                    const Ray made = camera_ray(f, row, column, chunk_sample0 + (chunk_next >> 6));
+                    pool[0][lane] = made.o.x; pool[1][lane] = made.o.y; pool[2][lane] = made.o.z;
+                    pool[3][lane] = made.d.x; pool[4][lane] = made.d.y; pool[5][lane] = made.d.z;
+                    pool_first = chunk_next;
+                    pool_taken = 0;
+                    chunk_next += 64;
                 }
                 const int rank = __popcll(m_need & ((1ull << lane) - 1ull));
-                const int available = chunk_size - chunk_next;
-                if (st == ST_NEED && rank < available) {
-                    const int j = chunk_next + rank;
-                    const int pixel = j & 63;
-                    const int row = chunk_row0 + (pixel >> 3);
-                    const int column = chunk_col0 + (pixel & 7);
-                    const int sample = chunk_sample0 + (j >> 6);
+                const int entry = pool_taken + rank;
+                if (st == ST_NEED && entry < 64) {
+                    const int row = chunk_row0 + (entry >> 3);
+                    const int column = chunk_col0 + (entry & 7);
                     if (row < f.row_end && column < f.width) {
-                        slot = (long long)chunk * CHUNK_PATHS + j;
-                        ray = camera_ray(f, row, column, sample);
+                        slot = (long long)chunk * CHUNK_PATHS + pool_first + entry;
+                        ray = Ray{D3{pool[0][entry], pool[1][entry], pool[2][entry]}, D3{pool[3][entry], pool[4][entry], pool[5][entry]}};
                         att = D3{1.0f, 1.0f, 1.0f};
                         bounce = 0;
                         st = ST_NEWRAY;
                     }
                     // a pixel outside the image (partial tile) is skipped; the lane asks again
                 }
-                const int taken = min(__popcll(m_need), available);
+                const int taken = min(__popcll(m_need), 64 - pool_taken);
                 if (STATS) ws.paths += taken;
-                chunk_next += taken;
+                pool_taken += taken;
             }
             if (STATS == 2) { const long long t1 = clock64(); ws.t_refill += t1 - t0; t0 = t1; }
             // ---------------- start the search of every new ray (src/path_tracing.cpp:177-178)
@@ -325,10 +341,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     const int top = max(sp - 1, 0);
                     const int pending = stack_ref[top * BLOCK_THREADS];
                     const int next = stuck ? pending : r0;
-                    // sp + 3 <= stack_slots holds for every node of a hierarchy the host has measured; the
-                    // test keeps a corrupted node from walking a lane out of its stack
-                    const bool done = (stuck && sp == 0) || (sp + 3 > w.stack_slots);
-                    st = done ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
+                    // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
+                    // waves per CU).  A lane about to outgrow its stack gives up the ordered search and is
+                    // resolved like a tie, by the exhaustive traversal, when it is shaded.
+                    const bool overflow = sp + 3 > w.stack_slots;
+                    tie = tie | overflow;
+                    st = ((stuck && sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
                     sp = stuck ? top : sp;
                     cur = next;
                 } else {

@@ -15,7 +15,8 @@ from pathtracer_amd import ctypes_abi as abi
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("PT_KERNEL", "PT_NODES", "PT_BVH", "PT_STATS", "PT_WORKSPACE_GB", "PT_SHADE_THRESHOLD", "PT_LEAF_THRESHOLD")
+SWITCHES = ("PT_KERNEL", "PT_NODES", "PT_BVH", "PT_STATS", "PT_WORKSPACE_GB", "PT_SHADE_THRESHOLD", "PT_LEAF_THRESHOLD",
+            "PT_STACK_SLOTS")
 
 
 @pytest.fixture
@@ -69,6 +70,19 @@ def test_sample_batches_do_not_change_the_sum(api, chess, switches):
     whole = api.DeviceScene.from_host(host).render(many)
     assert same_bits(batched, whole)
     assert (whole.reshape(-1, 4)[:, 3] == 37.0).all()
+
+
+@pytest.mark.parametrize("slots", [3, 6, 12])
+def test_a_lane_that_outgrows_its_stack_falls_back_to_the_exhaustive_search(api, chess, switches, slots):
+    """The 4-wide search keeps pending subtrees in a per-lane LDS stack that may be smaller than the
+    deepest search needs; a lane about to overflow is resolved by the exhaustive traversal instead.
+    With 3 slots every search overflows at once; the bytes must not change."""
+    host, frame, expect = chess
+    switches(PT_STACK_SLOTS=slots)
+    small = host.frame(64, 36, sample_count=2, max_bounces=8)
+    got = api.DeviceScene.from_host(host).render(small)
+    switches()
+    assert same_bits(got, api.DeviceScene.from_host(host).render(small))
 
 
 def test_single_precision_nodes_never_skip_what_the_exact_test_accepts(api, switches):
