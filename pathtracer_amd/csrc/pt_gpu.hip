@@ -283,7 +283,7 @@ D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
 struct PtScene {
     int device = 0;
     DeviceScene dev{};
-    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material, tri_quads, tri_quad_boxes, tri_leaves;
+    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material, tri_quads, tri_quad_boxes, tri_leaf_boxes;
     int tri_height = 0, sph_height = 0;
     int tri_stack_need = 1;             // slots of the wavefront kernel's stack a search of the 4-wide hierarchy can touch
     DeviceBuffer sph_pairs, sph_ref_nodes, spheres, sph_material, materials;
@@ -429,33 +429,23 @@ int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, Pt
         std::fprintf(stderr, "pathtracer_amd: %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", pairs.size(), quads.nodes.size(),
                      scene->tri_stack_need);
     }
-    std::vector<LeafRecord> leaves(d.triangle_count);
+    std::vector<LeafBox> leaf_boxes(d.triangle_count);
     for (int i = 0; i < d.triangle_count; ++i) {
-        using namespace pt;
-        const PtTriangle& t = d.triangles[i];
-        const PtAabb box = box_of(t);                      // the leaf's box exactly as the reference's BVH stores it
-        const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
-        const PtVec3 n = cross(ab, ac);
-        LeafRecord& r = leaves[i];
-        r.box[0] = box.min.x; r.box[1] = box.min.y; r.box[2] = box.min.z;
-        r.box[3] = box.max.x; r.box[4] = box.max.y; r.box[5] = box.max.z;
-        r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
-        r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
-        r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
-        r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
-        r.nn = dot(n, n);
-        r.pad_ = 0.0;
+        const PtAabb box = pt::box_of(d.triangles[i]);       // the leaf's box exactly as the reference's BVH stores it
+        double* b = leaf_boxes[i].box;
+        b[0] = box.min.x; b[1] = box.min.y; b[2] = box.min.z;
+        b[3] = box.max.x; b[4] = box.max.y; b[5] = box.max.z;
     }
     int rc = upload(scene->tri_quads, quads.nodes.data(), quads.nodes.size() * sizeof(QuadNode32));
     if (rc != PT_OK) return rc;
     rc = upload(scene->tri_quad_boxes, quads.exact.data(), quads.exact.size() * sizeof(QuadBoxes64));
     if (rc != PT_OK) return rc;
-    rc = upload(scene->tri_leaves, leaves.data(), leaves.size() * sizeof(LeafRecord));
+    rc = upload(scene->tri_leaf_boxes, leaf_boxes.data(), leaf_boxes.size() * sizeof(LeafBox));
     if (rc != PT_OK) return rc;
     scene->dev.tri_quads = scene->tri_quads.as<QuadNode32>();
     scene->dev.tri_quad_boxes = scene->tri_quad_boxes.as<QuadBoxes64>();
-    scene->dev.tri_leaves = scene->tri_leaves.as<LeafRecord>();
-    if (d.triangle_count == 1) scene->dev.tri_quads = reinterpret_cast<const QuadNode32*>(scene->dev.tri_leaves);   // no inner node exists; any non-null value enables the path
+    scene->dev.tri_boxes = scene->tri_leaf_boxes.as<LeafBox>();
+    if (quads.nodes.empty()) scene->dev.tri_quads = nullptr;    // a single triangle has no inner node: the exact-node path serves it
     return PT_OK;
 }
 

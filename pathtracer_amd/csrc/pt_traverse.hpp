@@ -35,7 +35,7 @@ struct TreeRef {
 // So which leaves the reference reaches depends only on each leaf's OWN box, and inner boxes
 // serve purely to skip subtrees.  They may therefore be tested conservatively in f32, as long
 // as no subtree is skipped that holds a leaf the exact test would accept within the pruning
-// distance; the exact f64 box test is then repeated at the leaf (LeafRecord::box).
+// distance; the exact f64 test of the leaf's own box decides (LeafBox).
 //
 // Conservative test: boxes are stored rounded outward; the lower plane is taken relative to
 // the origin rounded up and the upper plane relative to the origin rounded down, so before
@@ -53,14 +53,10 @@ struct QuadNode32 {
 static_assert(sizeof(QuadNode32) == 128, "QuadNode32 is one 128-byte line");
 struct QuadBoxes64 { double box[4][6]; };   // the exact child boxes, read only by the cross-checking build
 
-// Everything a leaf visit needs: the leaf's exact box, then the ray-independent part of the
-// triangle test (same fields as TriRecord without the unit normal).  160 B = ten 16-byte loads.
-struct LeafRecord {
-    double box[6];
-    double a[3], ab[3], ac[3], n[3], nn;
-    double pad_;
-};
-static_assert(sizeof(LeafRecord) == 160, "LeafRecord is ten 16-byte pieces");
+// A leaf's own box exactly as the reference's BVH stores it: the reference tests it before the
+// triangle (src/path_tracing.cpp:113-127).  The wavefront kernel tests the triangle alone and then
+// checks the box of the one triangle that won, when the path is shaded.
+struct LeafBox { double box[6]; };
 
 constexpr float RHO32 = 9.5367431640625e-07f;    // 2^-20
 constexpr float EPS32 = 1.0e-30f;
@@ -148,7 +144,7 @@ struct DeviceScene {
     const int32_t* tri_material;
     const QuadNode32* tri_quads;     // 4-wide single-precision hierarchy; null if the scene is out of f32 range
     const QuadBoxes64* tri_quad_boxes;
-    const LeafRecord* tri_leaves;
+    const LeafBox* tri_boxes;
     TreeRef sph_tree;
     const double* spheres;        // 4 doubles each
     const int32_t* sph_material;

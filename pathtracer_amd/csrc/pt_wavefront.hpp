@@ -134,6 +134,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
+                if (NODE32 && best_i >= 0) {
+                    // The reference reaches a triangle only through its leaf's box (src/path_tracing.cpp:113-127).
+                    // If the winner's box fails the exact test, some other triangle (or none) is the answer: the
+                    // exhaustive traversal finds it.  A ray that traversal has handled already (infinite
+                    // reciprocals) arrives here with a box it has tested itself.
+                    const double* b = s.tri_boxes[best_i].box;
+                    double tmin, tmax;
+                    slab_exact(ray.o, inv, b, tmin, tmax);
+                    tie = tie | (tmax < 0.0f) | (tmin > tmax);
+                }
                 resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
                 D3 gain;
                 const bool go_on = shade_vertex(s, ray, hs, ht, att, gain);
@@ -271,16 +281,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             if (st == ST_LEAF) {
                 const int primitive = ~cur;
                 double d;
-                bool hit;
-                if (NODE32) {
-                    const LeafRecord* leaf = s.tri_leaves + primitive;
-                    double tmin, tmax;
-                    slab_finite(ray.o, inv, leaf->box[0], leaf->box[1], leaf->box[2], leaf->box[3], leaf->box[4], leaf->box[5], tmin, tmax);
-                    const bool enter = !(tmax < 0.0f) & !(tmin > tmax) & !(tmin > cut);   // no short cut: one basic block
-                    hit = hit_triangle(ray, leaf, d) & enter;
-                } else {
-                    hit = hit_triangle(ray, s.tris + primitive, d);   // the box was tested exactly at the parent
-                }
+                // With the conservative nodes the leaf's own box has not been tested exactly yet; that test is
+                // made once, on the winning triangle, before the path is shaded.
+                const bool hit = hit_triangle(ray, s.tris + primitive, d);
                 const bool better = hit & (d < best_t);
                 const bool equal = hit & (d == best_t);
                 const bool closer = better & (d < hs.distance);
