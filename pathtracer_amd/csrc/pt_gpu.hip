@@ -498,15 +498,17 @@ struct Tunables {
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
-    int shade_threshold = 28;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
+    int shade_threshold = 32;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
     int leaf_threshold = 24;
     int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
+    int distrust_mask = 0x7fffffff;     // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winning triangle to the fallback)
     bool xcd_bands = false;             // PT_XCD=1: one chunk counter per XCD (tile rows dealt to the XCDs) instead of one for the chip
     Tunables() {
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
         if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
         if (const char* v = std::getenv("PT_XCD")) xcd_bands = std::atoi(v) != 0;
         if (const char* v = std::getenv("PT_STACK_SLOTS")) stack_slots = std::atoi(v);
+        if (const char* v = std::getenv("PT_DISTRUST_MASK")) distrust_mask = std::atoi(v);
         if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_LEAF_THRESHOLD")) leaf_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_KERNEL")) force_pixels_kernel = std::strcmp(v, "pixels") == 0;
@@ -606,6 +608,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.shade_threshold = t.shade_threshold;
         wp.leaf_threshold = t.leaf_threshold;
         wp.stack_slots = stack_slots;
+        wp.distrust_mask = t.distrust_mask;
         if (wp.chunk_count >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld chunks", wp.chunk_count);
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
         first = false;

@@ -43,6 +43,8 @@ struct WorkParams {
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
+    int distrust_mask;           // test aid: a winning triangle whose index has none of these bits set is sent to the
+                                 // exhaustive traversal as if its box test had failed (0x7fffffff = never)
 };
 
 // rgb layout: [chunk][channel r,g,b][CHUNK_PATHS] doubles; path j of a chunk is sample
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     const double* b = s.tri_boxes[best_i].box;
                     double tmin, tmax;
                     slab_exact(ray.o, inv, b, tmin, tmax);
-                    tie = tie | (tmax < 0.0f) | (tmin > tmax);
+                    tie = tie | (tmax < 0.0f) | (tmin > tmax) | ((best_i & w.distrust_mask) == 0);
                 }
                 resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
                 D3 gain;

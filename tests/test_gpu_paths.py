@@ -16,7 +16,7 @@ from pathtracer_amd import ctypes_abi as abi
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ("PT_KERNEL", "PT_NODES", "PT_BVH", "PT_STATS", "PT_WORKSPACE_GB", "PT_SHADE_THRESHOLD", "PT_LEAF_THRESHOLD",
-            "PT_STACK_SLOTS")
+            "PT_STACK_SLOTS", "PT_DISTRUST_MASK")
 
 
 @pytest.fixture
@@ -80,6 +80,18 @@ def test_a_lane_that_outgrows_its_stack_falls_back_to_the_exhaustive_search(api,
     host, frame, expect = chess
     switches(PT_STACK_SLOTS=slots)
     small = host.frame(64, 36, sample_count=2, max_bounces=8)
+    got = api.DeviceScene.from_host(host).render(small)
+    switches()
+    assert same_bits(got, api.DeviceScene.from_host(host).render(small))
+
+
+def test_a_winner_whose_box_test_fails_is_resolved_by_the_exhaustive_search(api, chess, switches):
+    """The leaf phase tests triangles without their boxes; the winner's box is tested before shading
+    and a failure sends the ray to the exhaustive traversal.  Real rays all but never fail it, so the
+    switch makes the kernel distrust every fourth winner: the bytes must not change."""
+    host, frame, expect = chess
+    switches(PT_DISTRUST_MASK=3)
+    small = host.frame(96, 54, sample_count=2, max_bounces=8)
     got = api.DeviceScene.from_host(host).render(small)
     switches()
     assert same_bits(got, api.DeviceScene.from_host(host).render(small))
