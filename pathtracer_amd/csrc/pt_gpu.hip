@@ -494,7 +494,7 @@ unsigned grid_blocks(const PtFrame& f) {
 struct Tunables {
     bool force_pixels_kernel = false;   // PT_KERNEL=pixels: always the one-lane-per-pixel kernel
     int stats = 0;                      // PT_STATS=1: phase/lane counters + box-test cross-check; 2: counters + per-section clocks
-    double workspace_gb = 16.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer
+    double workspace_gb = 24.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
@@ -558,7 +558,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     const Tunables t = tunables();
     const long long tiles_x = (frame->width + 7) / 8;
     const long long real_tiles = local_tiles(*frame);
-    const size_t bytes_per_group = static_cast<size_t>(real_tiles) * 3 * CHUNK_PATHS * sizeof(double);
+    const size_t bytes_per_group = static_cast<size_t>(real_tiles) * 4 * CHUNK_PATHS * sizeof(double);
     const size_t cap = static_cast<size_t>(t.workspace_gb * 1024.0 * 1024.0 * 1024.0);
     const int total_groups = (frame->sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
     int groups_per_batch = static_cast<int>(std::max<size_t>(1, cap / bytes_per_group));

@@ -47,9 +47,10 @@ struct WorkParams {
                                  // exhaustive traversal as if its box test had failed (0x7fffffff = never)
 };
 
-// rgb layout: [chunk][channel r,g,b][CHUNK_PATHS] doubles; path j of a chunk is sample
-// (j / 64) of the chunk's sample group at pixel (j % 64) of the chunk's tile.
-PT_DEV long long rgb_index(long long chunk, int channel, int j) { return (chunk * 3 + channel) * CHUNK_PATHS + j; }
+// rgb layout: [chunk][CHUNK_PATHS][r, g, b, 0] doubles, one 32-byte record per path, written whole
+// (two 16-byte stores that fill one 32-byte sector); path j of a chunk is sample (j / 64) of the
+// chunk's sample group at pixel (j % 64) of the chunk's tile.
+PT_DEV long long rgb_index(long long chunk, int channel, int j) { return (chunk * CHUNK_PATHS + j) * 4 + channel; }
 
 enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4 };
 
@@ -154,9 +155,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // every earlier vertex added +-0 (see the file header): colour = 0 + last term
                     const long long c = slot / CHUNK_PATHS;
                     const int j = (int)(slot % CHUNK_PATHS);
-                    rgb[rgb_index(c, 0, j)] = 0.0f + gain.x;
-                    rgb[rgb_index(c, 1, j)] = 0.0f + gain.y;
-                    rgb[rgb_index(c, 2, j)] = 0.0f + gain.z;
+                    double* record = rgb + rgb_index(c, 0, j);
+                    record[0] = 0.0f + gain.x;
+                    record[1] = 0.0f + gain.y;
+                    record[2] = 0.0f + gain.z;
+                    record[3] = 0.0;
                     st = ST_NEED;
                 } else {
                     st = ST_NEWRAY;
