@@ -178,6 +178,9 @@ int pt_tonemap_bgra8(const double* accum, int64_t pixel_count, int32_t sample_co
 /* write_pixel_data_to_file (src/main.cpp:179-212): raw RGBA8 (B and R swapped on
  * the way out), rows bottom-to-top, no header.  `bgra` is left unchanged. */
 int pt_write_pixel_data_file(const char* filename, const uint8_t* bgra, int64_t pixel_count);
+/* Convenience, not in the reference (its only image output is the headerless dump above):
+ * the same BGRA8 image as a binary PPM (P6), top row first, so that a viewer can open it. */
+int pt_write_ppm_file(const char* filename, const uint8_t* bgra, int32_t width, int32_t height);
 
 /* ---------------- the GPU path ---------------- */
 
@@ -196,6 +199,13 @@ int pt_render(PtScene* scene, const PtFrame* frame, double* accum);
  * enqueued on `hip_stream` (a hipStream_t; null = the default stream).  Returns
  * after the launch; the caller synchronises the stream. */
 int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
+
+/* The tone-map of src/main.cpp:1024-1034 on the GPU: `accum_device` (4*pixel_count
+ * doubles) and `bgra8_device` (4*pixel_count bytes) are in the HBM of `device`, the
+ * kernel is enqueued on `hip_stream`.  Same bytes as pt_tonemap_bgra8.  Lets a
+ * multi-GPU job gather 4 bytes per pixel instead of 32. */
+int pt_tonemap_device(int32_t device, const double* accum_device, int64_t pixel_count, int32_t sample_count,
+                      uint8_t* bgra8_device, void* hip_stream);
 
 /* First-bounce `ClosestShapeIntersection.index` of both traversals
  * (src/path_tracing.cpp:177-178) for sample frame->sample_begin, -1 = miss.

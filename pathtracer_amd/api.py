@@ -18,8 +18,8 @@ MODELS_DIR = os.path.join(os.path.dirname(_HERE), "assets", "models")
 EXPORTS = [
     "pt_last_error", "pt_load_triangles_file", "pt_save_triangles_file", "pt_free", "pt_construct_triangle_bvh",
     "pt_construct_sphere_bvh", "pt_rotation_matrix", "pt_look_at_matrix", "pt_camera_look_at", "pt_camera_frame",
-    "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8",
-    "pt_write_pixel_data_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
+    "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8", "pt_tonemap_device",
+    "pt_write_pixel_data_file", "pt_write_ppm_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_primary_hits", "pt_last_render_ms", "pt_last_render_stats", "pt_device_eval",
 ]
 
@@ -67,7 +67,9 @@ def lib():
         dll.pt_host_scene_desc.argtypes = [C.c_void_p, C.c_void_p]
         dll.pt_host_scene_camera.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         dll.pt_tonemap_bgra8.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        dll.pt_tonemap_device.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         dll.pt_write_pixel_data_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
+        dll.pt_write_ppm_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
         dll.pt_scene_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         dll.pt_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -142,9 +144,21 @@ def tonemap_bgra8(accum, sample_count):
     return out
 
 
+def tonemap_device(device, accum_ptr, pixel_count, sample_count, out_ptr, stream=None):
+    """GPU tone-map: device pointers (ints) of the f64 BGRA+count buffer and of the BGRA8 output."""
+    check(lib().pt_tonemap_device(int(device), C.c_void_p(accum_ptr), int(pixel_count), int(sample_count), C.c_void_p(out_ptr),
+                                  C.c_void_p(stream or 0)))
+
+
 def write_pixel_data_file(path, bgra8):
     bgra8 = np.ascontiguousarray(bgra8, np.uint8)
     check(lib().pt_write_pixel_data_file(os.fsencode(path), ptr(bgra8), bgra8.size // 4))
+
+
+def write_ppm_file(path, bgra8, width, height):
+    bgra8 = np.ascontiguousarray(bgra8, np.uint8)
+    assert bgra8.size == 4 * width * height
+    check(lib().pt_write_ppm_file(os.fsencode(path), ptr(bgra8), int(width), int(height)))
 
 
 class HostScene:

@@ -232,4 +232,27 @@ int pt_write_pixel_data_file(const char* filename, const uint8_t* bgra, int64_t 
     return PT_OK;
 }
 
+int pt_write_ppm_file(const char* filename, const uint8_t* bgra, int32_t width, int32_t height) {
+    if (filename == nullptr || bgra == nullptr || width <= 0 || height <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_write_ppm_file: bad argument");
+    // the buffer's row 0 is the bottom of the picture (src/main.cpp:90-97: v grows with the row and the
+    // camera's y axis); PPM wants the top row first
+    std::vector<uint8_t> rgb(3ull * width * height);
+    for (int32_t row = 0; row < height; ++row) {
+        const uint8_t* in = bgra + 4ull * (height - 1 - row) * width;
+        uint8_t* out = rgb.data() + 3ull * row * width;
+        for (int32_t column = 0; column < width; ++column) {
+            out[3 * column + 0] = in[4 * column + 2];
+            out[3 * column + 1] = in[4 * column + 1];
+            out[3 * column + 2] = in[4 * column + 0];
+        }
+    }
+    FILE* file = std::fopen(filename, "wb");
+    if (file == nullptr) return fail(PT_ERR_IO, "cannot create '%s': %s", filename, std::strerror(errno));
+    const bool header = std::fprintf(file, "P6\n%d %d\n255\n", width, height) > 0;
+    const size_t wrote = std::fwrite(rgb.data(), 1, rgb.size(), file);
+    const bool closed = std::fclose(file) == 0;
+    if (!header || wrote != rgb.size() || !closed) return fail(PT_ERR_IO, "short write on '%s'", filename);
+    return PT_OK;
+}
+
 }  // extern "C"

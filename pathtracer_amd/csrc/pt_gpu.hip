@@ -489,6 +489,18 @@ unsigned grid_blocks(const PtFrame& f) {
     return static_cast<unsigned>((local_tiles(f) + (BLOCK_THREADS / 64) - 1) / (BLOCK_THREADS / 64));
 }
 
+// src/main.cpp:1024-1034, one lane per pixel: level = std::min<real>(sqrt(sum / samples), 1.0f), byte =
+// (unsigned char)(255.0f * level), where a NaN level converts as on x86-64 (to INT_MIN, low byte 0).
+__global__ __launch_bounds__(BLOCK_THREADS) void tonemap_kernel(const double* __restrict__ accum, long long pixel_count, double samples,
+                                                               uchar4* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    if (i >= pixel_count) return;
+    const double2 bg = reinterpret_cast<const double2*>(accum)[2 * i];
+    const double r = accum[4 * i + 2];
+    auto level = [samples](double sum) { return (unsigned char)to_int_x86(255.0f * std_min(sqrt(sum / samples), 1.0f)); };
+    out[i] = uchar4{level(bg.x), level(bg.y), level(r), 255};
+}
+
 // Tunables read from the environment at every call (measurement and cross-checking aids, not
 // part of the interface): tests switch them between renders to compare the code paths.
 struct Tunables {
@@ -743,6 +755,22 @@ int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device,
     const int rc = check_frame(frame);
     if (rc != PT_OK) return rc;
     return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream));
+}
+
+int pt_tonemap_device(int32_t device, const double* accum_device, int64_t pixel_count, int32_t sample_count, uint8_t* bgra8_device,
+                      void* hip_stream) {
+    if (accum_device == nullptr || bgra8_device == nullptr || pixel_count < 0 || sample_count <= 0) {
+        return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_tonemap_device: bad argument");
+    }
+    if (pixel_count == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(device));
+    const long long blocks = (pixel_count + BLOCK_THREADS - 1) / BLOCK_THREADS;
+    if (blocks > 0x7fffffffll) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_tonemap_device: %lld pixels are too many", (long long)pixel_count);
+    hipLaunchKernelGGL(tonemap_kernel, dim3(static_cast<unsigned>(blocks)), dim3(BLOCK_THREADS), 0, static_cast<hipStream_t>(hip_stream),
+                       accum_device, static_cast<long long>(pixel_count), static_cast<double>(sample_count),
+                       reinterpret_cast<uchar4*>(bgra8_device));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
 }
 
 int pt_render(PtScene* scene, const PtFrame* frame, double* accum) {

@@ -5,7 +5,8 @@ each pixel is written by exactly one worker.  Here a rank plays the worker: rows
 blocks of PT_ROW_BLOCK, block b to rank b % world (PtFrame.shard_index / shard_count), so each
 pixel's samples are still summed by one owner in ascending order and the assembled buffer is
 byte-identical to a single-GPU render.  The only exchange is the final gather of each rank's
-rows to rank 0 (RCCL over xGMI on GPUs, gloo on CPU): 32 B per pixel, once per frame.
+rows to rank 0 (RCCL over xGMI on GPUs, gloo on CPU): 32 B per pixel, once per frame, or 4 B per
+pixel when only the tone-mapped image is wanted (`gather_image8`).
 """
 import torch
 import torch.distributed as dist
@@ -21,11 +22,12 @@ def shard_rows(height, rank, world, row_begin=0):
 
 
 def gather_rows(accum, height, width, rank, world, dst=0, group=None):
-    """accum: (height, width, 4) float64 tensor holding this rank's rows (others are ignored).
-    After the call rank `dst` holds every rank's rows in place; other ranks are unchanged."""
+    """accum: (height, width, 4) tensor (float64 sums, or uint8 image) holding this rank's rows
+    (others are ignored).  After the call rank `dst` holds every rank's rows in place; other ranks
+    are unchanged."""
     if world == 1:
         return accum
-    assert accum.shape == (height, width, 4) and accum.dtype == torch.float64
+    assert accum.shape == (height, width, 4)
     counts = [len(shard_rows(height, r, world)) for r in range(world)]
     longest = max(counts)
     mine = shard_rows(height, rank, world).to(accum.device)
@@ -42,3 +44,16 @@ def gather_rows(accum, height, width, rank, world, dst=0, group=None):
     else:
         dist.gather(send, None, dst=dst, group=group)
     return accum
+
+
+def gather_image8(accum, sample_count, height, width, rank, world, dst=0, group=None):
+    """Tone-maps this rank's rows where they are (src/main.cpp:1024-1034; on the GPU when `accum` is
+    there) and gathers the BGRA8 image to rank `dst`: an eighth of the bytes of `gather_rows`."""
+    from . import api
+    if accum.is_cuda:
+        image = torch.empty((height, width, 4), dtype=torch.uint8, device=accum.device)
+        api.tonemap_device(accum.device.index, accum.data_ptr(), height * width, sample_count, image.data_ptr(),
+                           torch.cuda.current_stream(accum.device).cuda_stream)
+    else:
+        image = torch.from_numpy(api.tonemap_bgra8(accum.contiguous().numpy(), sample_count)).reshape(height, width, 4)
+    return gather_rows(image, height, width, rank, world, dst=dst, group=group)

@@ -81,6 +81,24 @@ def test_device_scatter(api, golden):
     assert same_bits(api.device_eval(abi.PT_EVAL_SCATTER, records), golden["scatter_out"])
 
 
+def test_device_tonemap(api, golden):
+    """src/main.cpp:1024-1034 on the GPU against the host entry point and the reference-made image,
+    including sums a render cannot produce (negative, NaN, infinite, far above the sample count)."""
+    import torch
+    rng = np.random.default_rng(5)
+    odd = np.array([0.0, -0.0, 4.0, 3.999999999999999, 4.000000000000001, -1.0, np.nan, np.inf, 1e300, 1e-320, 2.25, 0.25])
+    accum = np.concatenate([golden["rook_accum4"].ravel(), rng.uniform(0, 6, 4 * 5000), np.resize(odd, 4 * 300)])
+    expect = api.tonemap_bgra8(accum, 4)
+    assert np.array_equal(expect[:golden["rook_bgra8"].size], golden["rook_bgra8"].ravel())
+    a = torch.from_numpy(accum).to("cuda:0")
+    out = torch.zeros(accum.size, dtype=torch.uint8, device="cuda:0")
+    api.tonemap_device(0, a.data_ptr(), accum.size // 4, 4, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), expect)
+    with pytest.raises(api.PathTracerError):
+        api.tonemap_device(0, a.data_ptr(), accum.size // 4, 0, out.data_ptr())
+
+
 # ------------------------------------------------------------------ primary hits: bit-exact triangle ids
 @pytest.mark.parametrize("name,size,key", [("rook", (64, 48), "rook"), ("pawn", (64, 36), "pawn")])
 def test_primary_hits_small(scenes, golden, name, size, key):

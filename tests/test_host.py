@@ -155,6 +155,13 @@ def test_tonemap_and_pixel_file(api, golden, tmp_path):
     assert np.array_equal(data[:, [2, 1, 0, 3]], bgra.reshape(-1, 4))     # RGBA on disk, rows untouched (bottom-up)
     with pytest.raises(api.PathTracerError):
         api.tonemap_bgra8(accum, 0)
+    # PPM convenience: header, RGB order, top row first
+    ppm = tmp_path / "image.ppm"
+    api.write_ppm_file(str(ppm), bgra, 64, 48)
+    raw = ppm.read_bytes()
+    assert raw.startswith(b"P6\n64 48\n255\n")
+    body = np.frombuffer(raw[len(b"P6\n64 48\n255\n"):], np.uint8).reshape(48, 64, 3)
+    assert np.array_equal(body[::-1], bgra.reshape(48, 64, 4)[:, :, [2, 1, 0]])
 
 
 def test_scene_create_rejects_bad_input_without_a_gpu(api):
