@@ -129,6 +129,11 @@ const char* pt_last_error(void);
 int pt_load_triangles_file(const char* filename, PtTriangle** triangles, int64_t* count);
 /* save_triangles_file (src/model_loading.cpp:41-61). */
 int pt_save_triangles_file(const char* filename, const PtTriangle* triangles, int64_t count);
+/* parse_stl_file (src/model_loading.cpp:63-196): ASCII STL -> triangles (facet normals are
+ * read and dropped, vertices converted with strtod).  The reference's asset converter; it
+ * asserts on malformed input, this returns PT_ERR_IO.  *triangles is malloc'ed (null if the
+ * file holds no facet); release with pt_free. */
+int pt_parse_stl_file(const char* filename, PtTriangle** triangles, int64_t* count);
 void pt_free(void* p);
 
 /* construct_triangle_bvh / construct_sphere_bvh (src/bvh.cpp:81-100 / :60-79).

@@ -203,6 +203,16 @@ def main():
         frame.sample_count = 4
         g[f"{name}_accum4"] = scene.render(frame)
 
+    # ---- the head of one of the reference's ASCII-STL assets (data): its first 60 facets; the expected
+    # triangles are the first 60 records of the matching .triangles asset
+    stl = open("/root/reference/models/stl/rook.stl", "rb").read()
+    end, facets = 0, 0
+    while facets < 60:
+        end = stl.index(b"endfacet", end) + len(b"endfacet")
+        facets += 1
+    with open(os.path.join(OUT, "rook_head.stl"), "wb") as f:
+        f.write(stl[:end] + b"\nendsolid OpenSCAD_Model\n")
+
     path = os.path.join(OUT, "reference_vectors.npz")
     np.savez_compressed(path, **g)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KiB, {len(g)} arrays")

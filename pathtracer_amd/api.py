@@ -16,7 +16,7 @@ LIBRARY_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
 MODELS_DIR = os.path.join(os.path.dirname(_HERE), "assets", "models")
 
 EXPORTS = [
-    "pt_last_error", "pt_load_triangles_file", "pt_save_triangles_file", "pt_free", "pt_construct_triangle_bvh",
+    "pt_last_error", "pt_load_triangles_file", "pt_save_triangles_file", "pt_parse_stl_file", "pt_free", "pt_construct_triangle_bvh",
     "pt_construct_sphere_bvh", "pt_rotation_matrix", "pt_look_at_matrix", "pt_camera_look_at", "pt_camera_frame",
     "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8", "pt_tonemap_device",
     "pt_write_pixel_data_file", "pt_write_ppm_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
@@ -56,6 +56,7 @@ def lib():
         dll.pt_scene_destroy.restype = None
         dll.pt_scene_destroy.argtypes = [C.c_void_p]
         dll.pt_load_triangles_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        dll.pt_parse_stl_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         dll.pt_save_triangles_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int64]
         dll.pt_construct_triangle_bvh.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         dll.pt_construct_sphere_bvh.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -91,6 +92,19 @@ def load_triangles_file(path):
     """(n, 9) float64 array of the file's triangles."""
     data, count = C.c_void_p(), C.c_int64()
     check(lib().pt_load_triangles_file(os.fsencode(path), C.byref(data), C.byref(count)))
+    try:
+        out = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_double)), shape=(count.value, 9)).copy()
+    finally:
+        lib().pt_free(data)
+    return out
+
+
+def parse_stl_file(path):
+    """(n, 9) float64 array of the triangles of an ASCII STL file."""
+    data, count = C.c_void_p(), C.c_int64()
+    check(lib().pt_parse_stl_file(os.fsencode(path), C.byref(data), C.byref(count)))
+    if count.value == 0:
+        return np.zeros((0, 9))
     try:
         out = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_double)), shape=(count.value, 9)).copy()
     finally:

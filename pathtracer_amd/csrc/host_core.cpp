@@ -132,6 +132,102 @@ int pt_save_triangles_file(const char* filename, const PtTriangle* triangles, in
     return PT_OK;
 }
 
+namespace {
+
+// A whitespace-separated word of the file (src/model_loading.cpp:74-89).
+struct Word {
+    const char* text;
+    size_t length;
+    // The reference compares only the word's own length (strncmp(word, keyword, word_length) == 0,
+    // src/model_loading.cpp:149-163), so a prefix of a keyword counts as the keyword.
+    bool is(const char* keyword) const { return std::strncmp(text, keyword, length) == 0; }
+};
+
+struct WordReader {
+    const std::vector<char>& bytes;
+    size_t at = 0;
+    static bool blank(char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
+    Word next() {
+        while (at < bytes.size() && blank(bytes[at])) ++at;
+        const size_t start = at;
+        while (at < bytes.size() && !blank(bytes[at])) ++at;
+        return Word{bytes.data() + start, at - start};
+    }
+    // parse_stl_vec3 (src/model_loading.cpp:91-108): three numbers read with strtod, each of which
+    // must use up its whole word
+    bool vec3(PtVec3* out) {
+        double v[3];
+        for (double& x : v) {
+            const Word w = next();
+            if (w.length == 0) return false;
+            char* end = nullptr;
+            x = std::strtod(w.text, &end);      // the buffer ends in a NUL, so the last word is terminated too
+            if (end != w.text + w.length) return false;
+        }
+        *out = PtVec3{v[0], v[1], v[2]};
+        return true;
+    }
+};
+
+}  // namespace
+
+int pt_parse_stl_file(const char* filename, PtTriangle** triangles, int64_t* count) {
+    if (filename == nullptr || triangles == nullptr || count == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "pt_parse_stl_file: null argument");
+    *triangles = nullptr;
+    *count = 0;
+    FILE* file = std::fopen(filename, "rb");
+    if (file == nullptr) return fail(PT_ERR_IO, "cannot open '%s': %s", filename, std::strerror(errno));
+    std::vector<char> bytes;
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = std::fread(chunk, 1, sizeof(chunk), file)) > 0) bytes.insert(bytes.end(), chunk, chunk + got);
+    const bool read_error = std::ferror(file) != 0;
+    std::fclose(file);
+    if (read_error) return fail(PT_ERR_IO, "read error on '%s'", filename);
+    bytes.push_back('\0');                      // the reference allocates size + 1 zeroed bytes (:128)
+    const size_t text_size = bytes.size() - 1;
+
+    // parse_stl_file (src/model_loading.cpp:138-188): "facet" opens a triangle, "vertex" fills a, b, c in
+    // turn, "loop" restarts the vertex count, the normal is read and ignored, other words are skipped.
+    // Where the reference asserts, this returns an error.
+    std::vector<PtTriangle> found;
+    WordReader reader{bytes};
+    bool in_facet = false;
+    int vertices = 0;
+    while (reader.at < text_size) {
+        const Word w = reader.next();
+        if (w.length == 0) break;
+        if (w.is("facet")) {
+            if (in_facet) return fail(PT_ERR_IO, "'%s': facet inside a facet (triangle %zu)", filename, found.size());
+            in_facet = true;
+            found.push_back(PtTriangle{});
+        } else if (w.is("endfacet")) {
+            if (!in_facet) return fail(PT_ERR_IO, "'%s': endfacet without facet", filename);
+            in_facet = false;
+        } else if (w.is("normal")) {
+            PtVec3 ignored;
+            if (!in_facet || !reader.vec3(&ignored)) return fail(PT_ERR_IO, "'%s': bad normal near triangle %zu", filename, found.size());
+        } else if (w.is("loop")) {
+            vertices = 0;
+        } else if (w.is("endloop")) {
+            if (vertices != 3) return fail(PT_ERR_IO, "'%s': a loop of %d vertices (triangle %zu)", filename, vertices, found.size());
+        } else if (w.is("vertex")) {
+            PtVec3 v;
+            if (!in_facet || vertices > 2 || !reader.vec3(&v)) return fail(PT_ERR_IO, "'%s': bad vertex near triangle %zu", filename, found.size());
+            PtTriangle& t = found.back();
+            (vertices == 0 ? t.a : vertices == 1 ? t.b : t.c) = v;
+            ++vertices;
+        }
+    }
+    if (!found.empty()) {
+        *triangles = static_cast<PtTriangle*>(std::malloc(found.size() * sizeof(PtTriangle)));
+        if (*triangles == nullptr) return fail(PT_ERR_IO, "out of memory for %zu triangles", found.size());
+        std::memcpy(*triangles, found.data(), found.size() * sizeof(PtTriangle));
+    }
+    *count = static_cast<int64_t>(found.size());
+    return PT_OK;
+}
+
 int pt_rotation_matrix(double angle, double axis_x, double axis_y, double axis_z, PtMat3* out) {
     if (out == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "pt_rotation_matrix: null output");
     *out = rotation(angle, axis_x, axis_y, axis_z);

@@ -142,6 +142,33 @@ def test_chess_scenes(api, golden):
     assert e.value.code == abi.PT_ERR_UNSUPPORTED
 
 
+def test_stl_parser_reproduces_the_reference_assets(api, tmp_path):
+    """parse_stl_file (src/model_loading.cpp:63-196) is how the reference's .triangles assets were
+    made from its .stl assets: parsing an .stl must give the bytes of the matching .triangles."""
+    head = api.parse_stl_file(os.path.join(ROOT, "tests", "golden", "rook_head.stl"))
+    rook = np.fromfile(os.path.join(MODELS, "rook.triangles")).reshape(-1, 9)
+    assert head.shape == (60, 9) and head.tobytes() == rook[:60].tobytes()
+    stl_dir = "/root/reference/models/stl"
+    if os.path.isdir(stl_dir):                      # the full assets, where the reference is present
+        for name, count in COUNTS.items():
+            parsed = api.parse_stl_file(os.path.join(stl_dir, name + ".stl"))
+            assert len(parsed) == count
+            assert parsed.tobytes() == np.fromfile(os.path.join(MODELS, name + ".triangles")).tobytes()
+    # round trip through the .triangles writer, and malformed input
+    out = tmp_path / "head.triangles"
+    api.save_triangles_file(str(out), head)
+    assert api.load_triangles_file(str(out)).tobytes() == head.tobytes()
+    bad = tmp_path / "bad.stl"
+    bad.write_text("solid x\n facet normal 0 0 1\n outer loop\n vertex 0 0 0\n vertex 1 0 zero\n")
+    with pytest.raises(api.PathTracerError) as e:
+        api.parse_stl_file(str(bad))
+    assert e.value.code == abi.PT_ERR_IO
+    two = tmp_path / "two.stl"
+    two.write_text("solid x\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nendloop\nendfacet\n")
+    with pytest.raises(api.PathTracerError):
+        api.parse_stl_file(str(two))
+
+
 def test_tonemap_and_pixel_file(api, golden, tmp_path):
     for name in ("rook", "pawn"):
         assert np.array_equal(api.tonemap_bgra8(golden[f"{name}_accum4"], 4), golden[f"{name}_bgra8"])
