@@ -27,7 +27,7 @@ struct TreeRef {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Single-precision inner nodes (64 B per pair) for the wavefront kernel.
+// Single-precision inner nodes (128 B, four children) for the wavefront kernel.
 //
 // For a ray whose reciprocals are finite, a box that lies inside another box passes the
 // reference's slab test only if the outer box passes it too, and its entry distance is no
@@ -42,9 +42,10 @@ struct TreeRef {
 // rounding the f32 slab interval contains the exact one; the three roundings per product
 // (subtract, reciprocal, multiply: 3 * 2^-24 relative) are covered by widening the interval by
 // RHO = 2^-20 relative plus EPS32 absolute (denormal range).
+//
 // Four children per node: a node of the binary hierarchy with its children (and, while slots are
 // free, the largest grandchildren) pulled up.  plane[k] holds the k-th bound (min x, y, z, max x, y,
-// z) of the four child boxes side by side; an empty slot has min > max and is never entered.
+// z) of the four child boxes side by side; an empty slot holds NaN and is never entered.
 struct QuadNode32 {
     float plane[6][4];
     int32_t child[4];      // >= 0: quad index, < 0: ~primitive
@@ -91,17 +92,8 @@ PT_DEV Ray32 make_ray32(const Ray& ray, D3 inv) {
 // Upper bound, as a float, of the pruning distance.
 PT_DEV float cut32_of(double cut) { return (float)((cut + 1.0e-30) * (1.0 + 4.76837158203125e-07)); }
 
-// Conservative bounds of one box: `lower` <= exact entry distance, `upper` >= exact exit distance.
-PT_DEV void slab32(const Ray32& r, float b0, float b1, float b2, float b3, float b4, float b5, float& lower, float& upper) {
-    const float x0 = (b0 - r.ohx) * r.ix, x1 = (b3 - r.olx) * r.ix;
-    const float y0 = (b1 - r.ohy) * r.iy, y1 = (b4 - r.oly) * r.iy;
-    const float z0 = (b2 - r.ohz) * r.iz, z1 = (b5 - r.olz) * r.iz;
-    const float tmin = fmaxf(fminf(z0, z1), fmaxf(fminf(y0, y1), fminf(x0, x1)));
-    const float tmax = fminf(fmaxf(z0, z1), fminf(fmaxf(y0, y1), fmaxf(x0, x1)));
-    lower = fmaf(fabsf(tmin), -RHO32, tmin);
-    upper = fmaf(fabsf(tmax), RHO32, tmax);
-}
-// All four child boxes at once on 4-wide vectors.
+// Conservative bounds of the four child boxes at once, on 4-wide vectors: `lower` <= exact entry
+// distance, `upper` >= exact exit distance.
 typedef float Float4 __attribute__((ext_vector_type(4)));
 PT_DEV Float4 min4(Float4 a, Float4 b) { return Float4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)}; }
 PT_DEV Float4 max4(Float4 a, Float4 b) { return Float4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
@@ -117,11 +109,6 @@ PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ q, Float4&
     upper = Float4{fmaf(fabsf(tmax.x), RHO32, tmax.x), fmaf(fabsf(tmax.y), RHO32, tmax.y),
                    fmaf(fabsf(tmax.z), RHO32, tmax.z), fmaf(fabsf(tmax.w), RHO32, tmax.w)};
 }
-// May the subtree be skipped?  Never true for a box the exact test accepts within `cut`.
-PT_DEV bool skip32(float lower, float upper, float cut32) {
-    return (upper < -EPS32) || (lower - upper > EPS32) || (lower > cut32);
-}
-
 // May the child be entered?  True for every box the exact test accepts within `cut`; false for NaN
 // bounds (empty slots).
 PT_DEV bool enter32(float lower, float upper, float cut32) {
