@@ -413,25 +413,62 @@ int collapse_to_quads(const std::vector<PairNode>& pairs, int pair, int pending,
     return index;
 }
 
-// Single-precision inner nodes (boxes rounded outward) and the leaf records of the wavefront
-// kernel.  Skipped, leaving tri_quads null, when a coordinate is outside the range in which
-// the f32 slab products are guaranteed finite.
-int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, PtScene* scene) {
-    const PtAabb& root = d.triangle_bvh[0].aabb;
-    const double extent[6] = {root.min.x, root.min.y, root.min.z, root.max.x, root.max.y, root.max.z};
+// The wavefront kernel's search hierarchy: 4-wide single-precision nodes (boxes rounded outward)
+// and every primitive's own exact box.  `tri_pairs` is the binary hierarchy over the triangles; when
+// the scene has more than one sphere, a binary SAH hierarchy over triangles and spheres together is
+// built here instead, so that one search finds both nearest hits.  Skipped, leaving tri_quads null
+// (the exact-node path then serves the scene), when a coordinate is outside the range in which the
+// f32 slab products are guaranteed finite, or when there is no inner node at all.
+int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pairs, bool reference_topology, PtScene* scene) {
+    DeviceScene& dev = scene->dev;
+    dev.tri_quads = nullptr;
+    dev.sphere_base = 0x7fffffff;
+    dev.search_count = d.triangle_count;
+    dev.search_root = dev.tri_tree.root;
+    std::memcpy(dev.search_box, dev.tri_tree.root_box, sizeof(dev.search_box));
+    const bool merge = d.sphere_count > 1 && !reference_topology && d.sphere_count + d.triangle_count > 2;
+
+    std::vector<PtAabb> own_boxes;       // every primitive's box exactly as the reference's BVH leaves store it
+    own_boxes.reserve(static_cast<size_t>(d.triangle_count) + (merge ? d.sphere_count : 0));
+    for (int i = 0; i < d.triangle_count; ++i) own_boxes.push_back(pt::box_of(d.triangles[i]));
+    if (merge) {
+        for (int i = 0; i < d.sphere_count; ++i) own_boxes.push_back(pt::box_of(d.spheres[i]));
+    }
+    if (own_boxes.empty()) return PT_OK;
+    PtAabb all = own_boxes[0];
+    for (const PtAabb& b : own_boxes) {
+        all.min.x = pt::min_of(all.min.x, b.min.x); all.min.y = pt::min_of(all.min.y, b.min.y); all.min.z = pt::min_of(all.min.z, b.min.z);
+        all.max.x = pt::max_of(all.max.x, b.max.x); all.max.y = pt::max_of(all.max.y, b.max.y); all.max.z = pt::max_of(all.max.z, b.max.z);
+    }
+    const double extent[6] = {all.min.x, all.min.y, all.min.z, all.max.x, all.max.y, all.max.z};
     for (double v : extent) {
         if (!(std::fabs(v) <= MAX_COORD32)) return PT_OK;      // also false for NaN
     }
+
+    std::vector<PairNode> merged_pairs;
+    const std::vector<PairNode>* pairs = &tri_pairs;
+    if (merge) {
+        std::vector<PairNodeHost> host_pairs;
+        int root = 0, height = 0;
+        if (pt::build_sah_pairs(own_boxes, WF_STACK_DEPTH + 1, &host_pairs, &root, &height) != PT_OK) {
+            pt::clear_error();
+            return PT_OK;
+        }
+        merged_pairs.resize(host_pairs.size());
+        std::memcpy(merged_pairs.data(), host_pairs.data(), host_pairs.size() * sizeof(PairNode));
+        pairs = &merged_pairs;
+    }
+    if (pairs->empty()) return PT_OK;
     QuadBuild quads;
-    if (!pairs.empty()) collapse_to_quads(pairs, 0, 0, &quads);
+    collapse_to_quads(*pairs, 0, 0, &quads);
     scene->tri_stack_need = quads.deepest_pending + 3;      // a visit writes up to three slots above the pending entries
     if (std::getenv("PT_VERBOSE") != nullptr) {
-        std::fprintf(stderr, "pathtracer_amd: %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", pairs.size(), quads.nodes.size(),
-                     scene->tri_stack_need);
+        std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", own_boxes.size(),
+                     merge ? " (triangles and spheres in one hierarchy)" : "", pairs->size(), quads.nodes.size(), scene->tri_stack_need);
     }
-    std::vector<LeafBox> leaf_boxes(d.triangle_count);
-    for (int i = 0; i < d.triangle_count; ++i) {
-        const PtAabb box = pt::box_of(d.triangles[i]);       // the leaf's box exactly as the reference's BVH stores it
+    std::vector<LeafBox> leaf_boxes(own_boxes.size());
+    for (size_t i = 0; i < own_boxes.size(); ++i) {
+        const PtAabb& box = own_boxes[i];
         double* b = leaf_boxes[i].box;
         b[0] = box.min.x; b[1] = box.min.y; b[2] = box.min.z;
         b[3] = box.max.x; b[4] = box.max.y; b[5] = box.max.z;
@@ -442,10 +479,13 @@ int build_f32_nodes(const PtSceneDesc& d, const std::vector<PairNode>& pairs, Pt
     if (rc != PT_OK) return rc;
     rc = upload(scene->tri_leaf_boxes, leaf_boxes.data(), leaf_boxes.size() * sizeof(LeafBox));
     if (rc != PT_OK) return rc;
-    scene->dev.tri_quads = scene->tri_quads.as<QuadNode32>();
-    scene->dev.tri_quad_boxes = scene->tri_quad_boxes.as<QuadBoxes64>();
-    scene->dev.tri_boxes = scene->tri_leaf_boxes.as<LeafBox>();
-    if (quads.nodes.empty()) scene->dev.tri_quads = nullptr;    // a single triangle has no inner node: the exact-node path serves it
+    dev.tri_quads = scene->tri_quads.as<QuadNode32>();
+    dev.tri_quad_boxes = scene->tri_quad_boxes.as<QuadBoxes64>();
+    dev.tri_boxes = scene->tri_leaf_boxes.as<LeafBox>();
+    dev.search_root = 0;                                     // the hierarchy's own numbering: its root is node 0
+    dev.search_count = static_cast<int32_t>(own_boxes.size());
+    std::memcpy(dev.search_box, extent, sizeof(dev.search_box));
+    if (merge) dev.sphere_base = d.triangle_count;
     return PT_OK;
 }
 
@@ -513,7 +553,7 @@ struct Tunables {
     int shade_threshold = 32;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams
     int leaf_threshold = 24;
     int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
-    int distrust_mask = 0x7fffffff;     // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winning triangle to the fallback)
+    int distrust_mask = -1;             // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winner to the fallback)
     bool xcd_bands = false;             // PT_XCD=1: one chunk counter per XCD (tile rows dealt to the XCDs) instead of one for the chip
     Tunables() {
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
@@ -537,10 +577,10 @@ int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_dev
     return PT_OK;
 }
 
-template <int STATS, bool NODE32>
+template <int STATS, bool NODE32, bool MERGED>
 int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
                        const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
-    auto kernel = trace_paths_kernel<STATS, NODE32>;
+    auto kernel = trace_paths_kernel<STATS, NODE32, MERGED>;
     if (blocks_per_cu != nullptr) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, BLOCK_THREADS, stack_bytes));
         return PT_OK;
@@ -550,19 +590,22 @@ int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, 
     return PT_OK;
 }
 
-// Dispatch over the two compile-time switches; with `blocks_per_cu` set it only queries occupancy.
+// Dispatch over the compile-time switches; with `blocks_per_cu` set it only queries occupancy.
+template <int STATS>
+int trace_paths_variant(bool node32, bool merged, unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev,
+                        const FrameParams& fp, const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats,
+                        int* blocks_per_cu) {
+    if (!node32) return launch_trace_paths<STATS, false, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    if (merged) return launch_trace_paths<STATS, true, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    return launch_trace_paths<STATS, true, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+}
+
 int trace_paths(int stats_build, bool node32, unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
                 const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
-    if (stats_build == 1) {
-        return node32 ? launch_trace_paths<1, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                      : launch_trace_paths<1, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
-    }
-    if (stats_build == 2) {
-        return node32 ? launch_trace_paths<2, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                      : launch_trace_paths<2, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
-    }
-    return node32 ? launch_trace_paths<0, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu)
-                  : launch_trace_paths<0, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    const bool merged = node32 && dev.sphere_base != 0x7fffffff;
+    if (stats_build == 1) return trace_paths_variant<1>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    if (stats_build == 2) return trace_paths_variant<2>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    return trace_paths_variant<0>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
 }
 
 // Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
@@ -684,12 +727,10 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
     std::unique_ptr<PtScene> scene(new PtScene());
     scene->device = device;
     int rc;
+    std::vector<PairNode> pairs;
     if (d->triangle_count > 0) {
-        std::vector<PairNode> pairs;
         rc = build_tree(d->triangle_bvh, d->triangle_bvh_node_count, d->triangle_count, "triangle", scene->tri_pairs, scene->tri_ref_nodes,
                         &scene->dev.tri_tree, &scene->tri_height, &pairs, !tunables().reference_topology);
-        if (rc != PT_OK) return rc;
-        rc = build_f32_nodes(*d, pairs, scene.get());
         if (rc != PT_OK) return rc;
         // ray-independent part of the triangle test, same operations as src/geometry.cpp:111-114, :124, :84-90
         std::vector<TriRecord> records(d->triangle_count);
@@ -726,6 +767,8 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
         scene->dev.spheres = scene->spheres.as<double>();
         scene->dev.sph_material = scene->sph_material.as<int32_t>();
     }
+    rc = build_search_nodes(*d, pairs, tunables().reference_topology, scene.get());
+    if (rc != PT_OK) return rc;
     scene->albedo_bounded = true;
     for (int i = 0; i < d->material_count; ++i) {
         const PtMaterial& m = d->materials[i];

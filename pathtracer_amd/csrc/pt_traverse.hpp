@@ -129,9 +129,16 @@ struct DeviceScene {
     TreeRef tri_tree;
     const TriRecord* tris;
     const int32_t* tri_material;
-    const QuadNode32* tri_quads;     // 4-wide single-precision hierarchy; null if the scene is out of f32 range
+    // The wavefront kernel's search hierarchy: 4-wide single-precision nodes over the triangles and, when
+    // the scene has more than one sphere, over the spheres too (one search finds both nearest hits).
+    // Primitive p of it is triangle p if p < sphere_base, else sphere p - sphere_base.
+    const QuadNode32* tri_quads;     // null if the scene is out of f32 range
     const QuadBoxes64* tri_quad_boxes;
-    const LeafBox* tri_boxes;
+    const LeafBox* tri_boxes;        // own box of every primitive of the hierarchy
+    int32_t sphere_base;             // INT_MAX when the spheres are not part of the hierarchy
+    int32_t search_root;             // child reference of the hierarchy's root (0, or ~primitive if there is one primitive)
+    int32_t search_count;            // primitives in the hierarchy
+    double search_box[6];            // exact box of everything in it
     TreeRef sph_tree;
     const double* spheres;        // 4 doubles each
     const int32_t* sph_material;

@@ -43,8 +43,8 @@ struct WorkParams {
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
-    int distrust_mask;           // test aid: a winning triangle whose index has none of these bits set is sent to the
-                                 // exhaustive traversal as if its box test had failed (0x7fffffff = never)
+    int distrust_mask;           // test aid: a winner whose index has none of these bits set is sent to the exhaustive
+                                 // traversal as if its box test had failed (negative = never)
 };
 
 // rgb layout: [chunk][CHUNK_PATHS][r, g, b, 0] doubles, one 32-byte record per path, written whole
@@ -69,13 +69,14 @@ struct WaveShared {
 
 // STATS: 0 = none; 1 = phase/lane counters and the f32-versus-f64 box-test cross-check; 2 = the
 // counters and shader-clock time per section (no cross-check, so the times are the product's).
+// MERGED (with NODE32 only): the hierarchy holds the spheres as well as the triangles.
 // NODE32: inner nodes are the 128-byte single-precision nodes with four children (conservative
 // test, exact test repeated at the leaf); otherwise the 128-byte double-precision pairs, whose
 // test is the reference's own.
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
-template <int STATS, bool NODE32>
+template <int STATS, bool NODE32, bool MERGED>
 __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_kernel(DeviceScene s, FrameParams f, WorkParams w,
                                                                     double* __restrict__ rgb,
                                                                     unsigned int* __restrict__ next_chunk,
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     int st = ST_NEED;
     int cur = 0, sp = 0, bounce = 0, best_i = -1;
     long long slot = 0;                 // chunk * CHUNK_PATHS + j of the lane's path
-    bool tie = false;
+    bool tie = false, tie_s = false;    // a second triangle / sphere at exactly the best triangle / sphere distance
     double best_t = REAL_MAX, cut = REAL_MAX;
     float cut32 = 0.0f;
     Hit hs{-1, REAL_MAX};
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
+                constexpr bool merged = NODE32 && MERGED;
                 if (NODE32 && best_i >= 0) {
                     // The reference reaches a triangle only through its leaf's box (src/path_tracing.cpp:113-127).
                     // If the winner's box fails the exact test, some other triangle (or none) is the answer: the
@@ -145,9 +147,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     const double* b = s.tri_boxes[best_i].box;
                     double tmin, tmax;
                     slab_exact(ray.o, inv, b, tmin, tmax);
-                    tie = tie | (tmax < 0.0f) | (tmin > tmax) | ((best_i & w.distrust_mask) == 0);
+                    tie = tie | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((best_i & w.distrust_mask) == 0));
                 }
-                resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
+                if (merged) {
+                    // Spheres found by the same search: the same check on the winning sphere's box.  Either
+                    // search was pruned with the other's hits, so a doubt about one sends both to the
+                    // exhaustive traversals.
+                    if (hs.index >= 0) {
+                        const double* b = s.tri_boxes[s.sphere_base + hs.index].box;
+                        double tmin, tmax;
+                        slab_exact(ray.o, inv, b, tmin, tmax);
+                        tie_s = tie_s | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((hs.index & w.distrust_mask) == 0));
+                    }
+                    tie = tie | tie_s;
+                    if (__ballot(tie) != 0ull) {
+                        resolve_slow_lanes(tie, ray, s.sph_tree, sph_leaf, frames, hs);
+                        if (s.tri_tree.count > 0) resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
+                    }
+                } else {
+                    resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
+                }
                 D3 gain;
                 const bool go_on = shade_vertex(s, ray, hs, ht, att, gain);
                 ++bounce;
@@ -236,43 +255,44 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- start the search of every new ray (src/path_tracing.cpp:177-178)
             if (st == ST_NEWRAY) {
                 inv = D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+                constexpr bool merged = NODE32 && MERGED;
+                int kind = classify_ray(ray, inv);
+                if (NODE32 && kind == RAY_FINITE && !ray32_allowed(ray, inv)) kind = RAY_EXACT_ONLY;
+                hs = Hit{-1, REAL_MAX};
                 if (s.sph_tree.count == 1) {
                     // one sphere: its node is the root and a leaf; the reference tests the box, then the sphere
                     // (src/path_tracing.cpp:113-127); min/max order matters only if a slab product is NaN
-                    hs = Hit{-1, REAL_MAX};
                     double tmin, tmax, d;
                     slab_exact(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
                     if (!(tmax < 0.0f || tmin > tmax) && hit_sphere(ray, s.spheres, d)) hs = Hit{0, d};
-                } else {
+                } else if (!merged || kind != RAY_FINITE) {
+                    // spheres outside the search hierarchy, or a ray the hierarchy cannot take: the lane walks
+                    // the sphere tree on its own
                     hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, stack_ref, frames);
                 }
                 best_i = -1;
                 best_t = REAL_MAX;
                 tie = false;
+                tie_s = false;
                 sp = 0;
                 st = ST_SHADE;                       // unless a search is started below
-                if (s.tri_tree.count > 0) {
-                    int kind = classify_ray(ray, inv);
-                    if (NODE32 && kind == RAY_FINITE && !ray32_allowed(ray, inv)) kind = RAY_EXACT_ONLY;
-                    if (kind == RAY_EXACT_ONLY) {
-                        Hit ht{-1, REAL_MAX};
-                        resolve_slow_lanes(true, ray, s.tri_tree, tri_leaf, frames, ht);
-                        best_i = ht.index;
-                        best_t = ht.distance;
-                    } else if (kind == RAY_FINITE) {
-                        // a triangle beyond the sphere hit cannot win (:183): the search may stop there
-                        cut = prune_cut(hs.distance);
-                        double tmin, tmax;
-                        const double* rb = s.tri_tree.root_box;
-                        slab_finite(ray.o, inv, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], tmin, tmax);
-                        if (!(tmax < 0.0f || tmin > tmax || tmin > cut)) {
-                            cur = s.tri_tree.root;
-                            st = (cur < 0) ? ST_LEAF : ST_NODE;
-                            if (NODE32) {
-                                r32 = make_ray32(ray, inv);
-                                cut32 = cut32_of(cut);
-                                if (cur >= 0) cur = 0;       // the 4-wide hierarchy has its own numbering; its root is node 0
-                            }
+                if (kind == RAY_EXACT_ONLY && s.tri_tree.count > 0) {
+                    Hit ht{-1, REAL_MAX};
+                    resolve_slow_lanes(true, ray, s.tri_tree, tri_leaf, frames, ht);
+                    best_i = ht.index;
+                    best_t = ht.distance;
+                } else if (kind == RAY_FINITE && (NODE32 ? s.search_count : s.tri_tree.count) > 0) {
+                    // a triangle beyond the sphere hit cannot win (:183): the search may stop there
+                    cut = prune_cut(hs.distance);
+                    double tmin, tmax;
+                    const double* rb = NODE32 ? s.search_box : s.tri_tree.root_box;
+                    slab_finite(ray.o, inv, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], tmin, tmax);
+                    if (!(tmax < 0.0f || tmin > tmax || tmin > cut)) {
+                        cur = NODE32 ? s.search_root : s.tri_tree.root;
+                        st = (cur < 0) ? ST_LEAF : ST_NODE;
+                        if (NODE32) {
+                            r32 = make_ray32(ray, inv);
+                            cut32 = cut32_of(cut);
                         }
                     }
                 }
@@ -285,19 +305,43 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // Straight-line code: the whole record is fetched at once and the outcome applied with selects.
             if (st == ST_LEAF) {
                 const int primitive = ~cur;
-                double d;
                 // With the conservative nodes the leaf's own box has not been tested exactly yet; that test is
-                // made once, on the winning triangle, before the path is shaded.
-                const bool hit = hit_triangle(ray, s.tris + primitive, d);
-                const bool better = hit & (d < best_t);
-                const bool equal = hit & (d == best_t);
-                const bool closer = better & (d < hs.distance);
-                const double cut_d = prune_cut(d);
-                tie = (tie & !better) | equal;
-                best_t = better ? d : best_t;
-                best_i = better ? primitive : best_i;
-                cut = closer ? cut_d : cut;
-                if (NODE32) cut32 = closer ? cut32_of(cut_d) : cut32;
+                // made once, on the winning primitive, before the path is shaded.
+                if (NODE32 && MERGED) {
+                    const bool is_sphere = primitive >= s.sphere_base;
+                    double d = 0.0;
+                    bool hit = false;
+                    if (is_sphere) hit = hit_sphere(ray, s.spheres + 4 * (primitive - s.sphere_base), d);
+                    else hit = hit_triangle(ray, s.tris + primitive, d);
+                    // nearest triangle and nearest sphere are kept apart (the reference compares them only at
+                    // the end, src/path_tracing.cpp:183); both prune the one search
+                    const double own = is_sphere ? hs.distance : best_t;
+                    const double other = is_sphere ? best_t : hs.distance;
+                    const bool better = hit & (d < own);
+                    const bool equal = hit & (d == own);
+                    const bool closer = better & (d < other);
+                    const double cut_d = prune_cut(d);
+                    tie = is_sphere ? tie : ((tie & !better) | equal);
+                    tie_s = is_sphere ? ((tie_s & !better) | equal) : tie_s;
+                    best_t = (better & !is_sphere) ? d : best_t;
+                    best_i = (better & !is_sphere) ? primitive : best_i;
+                    hs.distance = (better & is_sphere) ? d : hs.distance;
+                    hs.index = (better & is_sphere) ? primitive - s.sphere_base : hs.index;
+                    cut = closer ? cut_d : cut;
+                    cut32 = closer ? cut32_of(cut_d) : cut32;
+                } else {
+                    double d;
+                    const bool hit = hit_triangle(ray, s.tris + primitive, d);
+                    const bool better = hit & (d < best_t);
+                    const bool equal = hit & (d == best_t);
+                    const bool closer = better & (d < hs.distance);
+                    const double cut_d = prune_cut(d);
+                    tie = (tie & !better) | equal;
+                    best_t = better ? d : best_t;
+                    best_i = better ? primitive : best_i;
+                    cut = closer ? cut_d : cut;
+                    if (NODE32) cut32 = closer ? cut32_of(cut_d) : cut32;
+                }
                 pop_once();
             }
             if (STATS == 2) ws.t_leaf += clock64() - t0;

@@ -110,6 +110,60 @@ def test_single_precision_nodes_never_skip_what_the_exact_test_accepts(api, swit
     assert stats["unsafe_skips"] == 0
 
 
+@pytest.fixture(scope="module")
+def both_kinds(api, orc):
+    """Triangles AND many spheres (a chess row with the reference's 488 random spheres around it): the
+    wavefront kernel searches them in one hierarchy."""
+    from oracle.bindings import make_desc
+    row = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS).arrays()
+    balls = api.HostScene(abi.PT_SCENE_RANDOM_SPHERES).arrays()
+    spheres = balls["spheres"].copy()
+    spheres[1:, :3] = spheres[1:, :3] * 12.0 + np.array([0.0, 20.0, 0.0])      # spread over the pieces
+    spheres[1:, 3] *= 12.0
+    spheres[0] = [0.0, -1000.0, 0.0, 1000.0]
+    arrays = dict(row)
+    arrays["materials"] = np.concatenate([row["materials"], balls["materials"]])
+    arrays["spheres"] = spheres
+    arrays["sphere_material_indices"] = (balls["sphere_material_indices"] + len(row["materials"])).astype(np.int32)
+    arrays["sphere_bvh"] = api.construct_sphere_bvh(spheres)
+    arrays["background"] = balls["background"]
+    host = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
+    frame = host.frame(96, 54, sample_count=3, max_bounces=12)
+    expect = orc.scene_create(arrays).render(frame, threads=8)
+    return arrays, frame, expect, make_desc
+
+
+@pytest.mark.parametrize("setting", [{}, {"PT_NODES": "f64"}, {"PT_KERNEL": "pixels"}, {"PT_DISTRUST_MASK": 1}, {"PT_STACK_SLOTS": 5},
+                                     {"PT_STATS": 1}, {"PT_BVH": "reference"}])
+def test_triangles_and_spheres_in_one_hierarchy(api, both_kinds, switches, setting):
+    arrays, frame, expect, make_desc = both_kinds
+    switches(**setting)
+    desc, keep = make_desc(arrays)
+    device = api.DeviceScene(desc, keepalive=keep)
+    got = device.render(frame)
+    if setting.get("PT_STATS") == 1:
+        assert device.last_render_stats()["unsafe_skips"] == 0
+    switches()
+    assert same_bits(got, expect)
+    tri, sph = device.primary_hits(frame)
+    assert (tri >= 0).any() and (sph > 0).any()
+
+
+@pytest.mark.parametrize("setting", [{"PT_DISTRUST_MASK": 0}, {"PT_STACK_SLOTS": 3}, {"PT_STATS": 1}])
+def test_sphere_only_scene_through_every_fallback(api, orc, switches, setting):
+    """The reference's random-spheres scene has no triangle: every path ends at a sphere or the sky.
+    PT_DISTRUST_MASK=0 sends every winner to the exhaustive traversal."""
+    host = api.HostScene(abi.PT_SCENE_RANDOM_SPHERES)
+    frame = host.frame(72, 48, sample_count=2, max_bounces=10)
+    switches(**setting)
+    device = api.DeviceScene.from_host(host)
+    got = device.render(frame)
+    if setting.get("PT_STATS") == 1:
+        assert device.last_render_stats()["unsafe_skips"] == 0
+    switches()
+    assert same_bits(got, orc.scene_create(host.arrays()).render(frame, threads=8))
+
+
 def test_thresholds_only_change_scheduling(api, chess, switches):
     host, frame, expect = chess
     device = api.DeviceScene.from_host(host)
