@@ -426,7 +426,13 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
     dev.search_count = d.triangle_count;
     dev.search_root = dev.tri_tree.root;
     std::memcpy(dev.search_box, dev.tri_tree.root_box, sizeof(dev.search_box));
-    const bool merge = d.sphere_count > 1 && !reference_topology && d.sphere_count + d.triangle_count > 2;
+    // A hollow sphere (negative radius, src/path_tracing.cpp:190) has an inverted box (src/geometry.cpp:51-57),
+    // and the boxes the reference builds above it (min of minima, max of maxima, :38-49) need not contain it:
+    // which rays reach it then depends on the reference's own tree.  Such spheres stay out of this
+    // library's hierarchy; the reference's sphere tree is walked as it is.
+    bool proper_spheres = true;
+    for (int i = 0; i < d.sphere_count; ++i) proper_spheres = proper_spheres && d.spheres[i].radius >= 0.0;
+    const bool merge = d.sphere_count > 1 && proper_spheres && !reference_topology && d.sphere_count + d.triangle_count > 2;
 
     std::vector<PtAabb> own_boxes;       // every primitive's box exactly as the reference's BVH leaves store it
     own_boxes.reserve(static_cast<size_t>(d.triangle_count) + (merge ? d.sphere_count : 0));

@@ -1,0 +1,110 @@
+"""Small synthetic scenes at the edges of the GPU path's code paths, each against the CPU checker,
+bit for bit: no primitive at all, one and two triangles (a 4-wide node with empty slots), degenerate
+triangles, coordinates outside the single-precision range, hollow spheres, spheres only.
+"""
+import numpy as np
+import pytest
+
+from conftest import same_bits
+from pathtracer_amd import ctypes_abi as abi
+
+pytestmark = pytest.mark.gpu
+
+SKY = np.array([[1.0, 1.0, 1.0], [0.5, 0.7, 1.0]])
+
+
+def _materials():
+    m = np.zeros(4, abi.MATERIAL_DTYPE)
+    m[0]["v"] = [0.8, 0.6, 0.4, 0.0]                                   # lambertian
+    m[1]["v"] = [0.9, 0.9, 0.8, 0.2]; m[1]["type"] = abi.PT_METAL
+    m[2]["v"] = [1.5, 0.0, 0.0, 0.0]; m[2]["type"] = abi.PT_DIELECTRIC
+    m[3]["v"] = [1.0, 0.9, 0.8, 5.0]; m[3]["type"] = abi.PT_DIFFUSE_LIGHT
+    return m
+
+
+def _scene(api, triangles=None, spheres=None, tri_materials=None, sph_materials=None):
+    triangles = np.zeros((0, 9)) if triangles is None else np.asarray(triangles, float).reshape(-1, 9)
+    spheres = np.zeros((0, 4)) if spheres is None else np.asarray(spheres, float).reshape(-1, 4)
+    arrays = {"materials": _materials(), "triangles": triangles, "spheres": spheres, "background": SKY,
+              "triangle_material_indices": np.asarray(tri_materials if tri_materials is not None else np.arange(len(triangles)) % 4, np.int32),
+              "sphere_material_indices": np.asarray(sph_materials if sph_materials is not None else np.arange(len(spheres)) % 3, np.int32)}
+    if len(triangles):
+        arrays["triangle_bvh"] = api.construct_triangle_bvh(triangles)
+    if len(spheres):
+        arrays["sphere_bvh"] = api.construct_sphere_bvh(spheres)
+    return arrays
+
+
+def _compare(api, orc, arrays, eye, target, size=(40, 30), spp=3, bounces=12, aperture=0.05):
+    from oracle.bindings import make_desc
+    desc, keep = make_desc(arrays)
+    device = api.DeviceScene(desc, keepalive=keep)
+    checker = orc.scene_create(arrays)
+    cam = api.camera_look_at(eye, target, 0.7, aperture)
+    frame = api.camera_frame(cam, size[0] / size[1], size[0], size[1], sample_count=spp, max_bounces=bounces)
+    tri, sph = device.primary_hits(frame)
+    tri_c, sph_c = checker.primary_hits(frame)
+    assert np.array_equal(tri, tri_c) and np.array_equal(sph, sph_c)
+    assert same_bits(device.render(frame), checker.render(frame, threads=4))
+    return tri, sph
+
+
+def test_scene_without_primitives_is_all_background(api, orc):
+    tri, sph = _compare(api, orc, _scene(api), (0.0, 1.0, 5.0), (0.0, 0.0, 0.0))
+    assert (tri == -1).all() and (sph == -1).all()
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 5])
+def test_few_triangles(api, orc, count):
+    """1: no inner node at all; 2, 3: one 4-wide node with two / one empty slots; 5: two levels."""
+    rng = np.random.default_rng(count)
+    triangles = rng.uniform(-3, 3, (count, 9))
+    tri, _ = _compare(api, orc, _scene(api, triangles, tri_materials=[0, 3, 1, 2, 0][:count]), (0.0, 0.0, 12.0), (0.0, 0.0, 0.0))
+    assert (tri >= 0).any()
+
+
+def test_degenerate_triangles_are_never_hit(api, orc):
+    """Zero-area triangles divide by n.n = 0 (src/geometry.cpp:124-126): NaN barycentrics, no hit; they
+    still sit in the hierarchy with flat boxes."""
+    rng = np.random.default_rng(3)
+    good = rng.uniform(-4, 4, (40, 9))
+    point = np.tile(rng.uniform(-4, 4, (10, 3)), 3)
+    a, b = rng.uniform(-4, 4, (10, 3)), rng.uniform(-4, 4, (10, 3))
+    line = np.concatenate([a, b, a + 0.5 * (b - a)], axis=1)
+    triangles = np.concatenate([good, point, line])
+    tri, _ = _compare(api, orc, _scene(api, triangles, tri_materials=np.zeros(60, np.int32)), (0.0, 0.0, 15.0), (0.0, 0.0, 0.0), spp=2)
+    assert (tri >= 0).any() and not (tri >= 40).any()
+
+
+def test_coordinates_outside_the_single_precision_range(api, orc):
+    """Boxes beyond 2^20 make the library keep the exact double-precision nodes for the whole scene."""
+    rng = np.random.default_rng(8)
+    triangles = rng.uniform(-3, 3, (200, 9)) * 1.0e6 + np.tile([4.0e7, -2.0e7, 1.0e7], 3)
+    tri, _ = _compare(api, orc, _scene(api, triangles), (4.0e7, -2.0e7, 4.0e7), (4.0e7, -2.0e7, 1.0e7), aperture=1.0e3)
+    assert (tri >= 0).any()
+
+
+@pytest.mark.parametrize("hollow", [False, True])
+def test_spheres_only(api, orc, hollow):
+    """Several spheres and no triangle: the search hierarchy holds spheres alone.  Negative radii are
+    the reference's hollow spheres (src/path_tracing.cpp:190-191); their boxes are inverted
+    (src/geometry.cpp:51-57) and the reference's own inner boxes decide what reaches them, so such a
+    scene walks the reference's sphere tree instead."""
+    rng = np.random.default_rng(21)
+    centres = rng.uniform(-4, 4, (30, 3))
+    radii = rng.uniform(0.3, 1.2, 30) * (rng.choice([1.0, 1.0, -1.0], 30) if hollow else 1.0)
+    spheres = np.concatenate([centres, radii[:, None]], axis=1)
+    shell = -1.4 if hollow else 1.4
+    spheres = np.concatenate([spheres, [[0.0, -104.0, 0.0, 100.0], [0.0, 1.0, 0.0, 1.5], [0.0, 1.0, 0.0, shell]]])   # ground, glass shell
+    sph_materials = np.concatenate([np.arange(30) % 3, [0, 2, 2]])
+    _, sph = _compare(api, orc, _scene(api, spheres=spheres, sph_materials=sph_materials), (0.0, 3.0, 14.0), (0.0, 0.0, 0.0), spp=4, bounces=20)
+    assert (sph >= 0).any()
+
+
+def test_two_spheres_and_two_triangles(api, orc):
+    """The smallest scene whose spheres join the triangles in one hierarchy."""
+    triangles = [[-5.0, -1.0, -5.0, 5.0, -1.0, -5.0, 0.0, -1.0, 5.0], [-2.0, 0.0, -3.0, 2.0, 0.0, -3.0, 0.0, 3.0, -3.0]]
+    spheres = [[-1.5, 0.0, 0.0, 1.0], [1.5, 0.0, 0.0, 1.0]]
+    tri, sph = _compare(api, orc, _scene(api, triangles, spheres, tri_materials=[0, 3], sph_materials=[1, 2]), (0.0, 2.0, 9.0), (0.0, 0.0, 0.0),
+                        size=(48, 36), spp=4, bounces=16)
+    assert (tri >= 0).any() and (sph == 0).any() and (sph == 1).any()
