@@ -12,6 +12,7 @@
 // range nobody reads again and is not reproduced.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -54,8 +55,12 @@ struct Build {
     }
 
     // Fills node `self` and its whole subtree; returns nothing, the box is read back from nodes[self].
-    // With `defer` set, subtrees smaller than `defer_below` are queued instead of built.
-    void fill(int self, int axis, int begin, int end, std::vector<Job>* deferred, int defer_below) const {
+    // With `deferred` set, subtrees smaller than `defer_below` are queued instead of built, and the two
+    // halves of a node above them are handled by two threads down to `fork_levels` levels (each
+    // std::sort call still sees exactly the sequence the serial build would give it, so ties fall the
+    // same way).
+    void fill(int self, int axis, int begin, int end, std::vector<Job>* deferred, int defer_below, int fork_levels = 0,
+              std::mutex* deferred_lock = nullptr) const {
         PtBvhNode& node = nodes[self];
         const int count = end - begin;
         if (count == 1) {
@@ -67,7 +72,9 @@ struct Build {
             return;
         }
         if (deferred != nullptr && count < defer_below) {
+            if (deferred_lock != nullptr) deferred_lock->lock();
             deferred->push_back(Job{self, axis, begin, end});
+            if (deferred_lock != nullptr) deferred_lock->unlock();
             return;
         }
         sort_range(axis, begin, end);
@@ -75,8 +82,14 @@ struct Build {
         const int mid = begin + count / 2;
         const int left = self + 1;
         const int right = self + 2 * (mid - begin);
-        fill(left, next_axis, begin, mid, deferred, defer_below);
-        fill(right, next_axis, mid, end, deferred, defer_below);
+        if (deferred != nullptr && fork_levels > 0) {
+            std::thread other([&]() { fill(left, next_axis, begin, mid, deferred, defer_below, fork_levels - 1, deferred_lock); });
+            fill(right, next_axis, mid, end, deferred, defer_below, fork_levels - 1, deferred_lock);
+            other.join();
+        } else {
+            fill(left, next_axis, begin, mid, deferred, defer_below, 0, deferred_lock);
+            fill(right, next_axis, mid, end, deferred, defer_below, 0, deferred_lock);
+        }
         node.index = 0;
         node.left = left;
         node.right = right;
@@ -114,11 +127,15 @@ void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads) 
         build.fill(0, 0, 0, count, nullptr, 0);
         return;
     }
-    // Serial top of the tree down to subtrees of < count/(4*threads) primitives, then one
-    // queue of independent subtrees shared by the workers.
+    // The top of the tree down to subtrees of < count/(4*threads) primitives (its first levels forked
+    // over threads: the root's sort is the one serial step), then one queue of independent subtrees
+    // shared by the workers.
     const int defer_below = std::max(2, count / (4 * threads));
     std::vector<Job> jobs;
-    build.fill(0, 0, 0, count, &jobs, defer_below);
+    std::mutex jobs_lock;
+    int fork_levels = 0;
+    while ((1 << (fork_levels + 1)) <= threads) ++fork_levels;
+    build.fill(0, 0, 0, count, &jobs, defer_below, fork_levels, &jobs_lock);
     std::atomic<size_t> next{0};
     auto worker = [&]() {
         for (;;) {
