@@ -190,7 +190,7 @@ class HostScene:
         self.aspect_ratio = aspect.value
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:       # at interpreter shutdown the module globals may be gone
             lib().pt_host_scene_destroy(self.handle)
             self.handle = None
 
@@ -236,7 +236,7 @@ class DeviceScene:
         return cls(host_scene.desc, device)
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:       # at interpreter shutdown the module globals may be gone
             lib().pt_scene_destroy(self.handle)
             self.handle = None
 

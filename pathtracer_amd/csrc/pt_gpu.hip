@@ -325,7 +325,7 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
         std::vector<PairNodeHost> host_pairs;
         int sah_root = 0, sah_height = 0;
         static_assert(sizeof(PairNodeHost) == sizeof(PairNode), "host and device pair nodes must match");
-        if (pt::build_sah_pairs(boxes, WF_STACK_DEPTH + 1, &host_pairs, &sah_root, &sah_height) == PT_OK) {
+        if (pt::build_sah_pairs(boxes, MAX_SEARCH_HEIGHT, &host_pairs, &sah_root, &sah_height) == PT_OK) {
             pairs.resize(host_pairs.size());
             std::memcpy(pairs.data(), host_pairs.data(), host_pairs.size() * sizeof(PairNode));
             root = sah_root;
@@ -456,7 +456,7 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
     if (merge) {
         std::vector<PairNodeHost> host_pairs;
         int root = 0, height = 0;
-        if (pt::build_sah_pairs(own_boxes, WF_STACK_DEPTH + 1, &host_pairs, &root, &height) != PT_OK) {
+        if (pt::build_sah_pairs(own_boxes, MAX_SEARCH_HEIGHT, &host_pairs, &root, &height) != PT_OK) {
             pt::clear_error();
             return PT_OK;
         }
