@@ -37,8 +37,9 @@ def algorithmic_work(scene, width, height, max_bounces):
     table = json.load(open(os.path.join(ROOT, "profiles", "algorithmic_work.json")))
     key = f"{scene}_{width}x{height}_depth{max_bounces}"
     if key not in table:
-        # per-sample work barely depends on resolution; fall back to the scene's 1080p entry
-        key = f"{scene}_1920x1080_depth{max_bounces}"
+        # per-sample work barely depends on resolution; fall back to the scene's entry at another size
+        others = [k for k in sorted(table) if k.startswith(scene + "_") and k.endswith(f"_depth{max_bounces}")]
+        key = others[0] if others else key
     return table.get(key, {}).get("per_sample"), key
 
 

@@ -31,7 +31,8 @@ from oracle.bindings import OracleLib  # noqa: E402
 from pathtracer_amd import api, ctypes_abi as abi  # noqa: E402
 from pathtracer_amd.ctypes_abi import ptr  # noqa: E402
 
-SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED}
+SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
+          "spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}
 NAMES = ["samples", "bounces", "triangle_nodes", "triangle_tests", "sphere_nodes", "sphere_tests", "ties", "pruned_mismatch"]
 
 
