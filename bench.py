@@ -154,7 +154,7 @@ def main():
             valu = {"bound": "fp64 valu (no FMA)", "achieved": tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tops/s",
                     "frac": tops / FP64_VALU_PEAK_TOPS, "algorithmic_f64_ops_per_sample": work["f64_ops"]}
         line = {
-            "metric": "Msamples/sec (whole node), chess set 1080p 256spp",
+            "metric": "Msamples/sec (whole node), chess set 1080p 256spp at 1/2/4/8 MI355X",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64",

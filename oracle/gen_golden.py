@@ -203,6 +203,14 @@ def main():
         frame.sample_count = 4
         g[f"{name}_accum4"] = scene.render(frame)
 
+    # ---- the plumbing configuration in full: pawn model scene, 640x360 (aspect 640/360), samples 0..15, depth 50
+    scene, cam, aspect = ref.model_scene(os.path.join(MODELS, "pawn.triangles"))
+    frame = ref.camera_frame(cam, 640 / 360, 640, 360)
+    frame.sample_count = 16
+    accum = scene.render(frame, threads=8)
+    g["pawn640_accum16_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(accum).tobytes()).digest(), np.uint8)
+    g["pawn640_accum16_sum"] = np.array([accum.reshape(-1, 4)[:, c].sum() for c in range(4)])
+
     # ---- the head of one of the reference's ASCII-STL assets (data): its first 60 facets; the expected
     # triangles are the first 60 records of the matching .triangles asset
     stl = open("/root/reference/models/stl/rook.stl", "rb").read()

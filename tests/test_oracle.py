@@ -82,6 +82,18 @@ def test_reference_builtin_scene_render(orc, golden, name, index, size):
     assert same_bits(scene.render(frame), golden[f"{name}_accum4"])
 
 
+def test_plumbing_configuration_in_full(orc, golden):
+    """Single pawn model in the reference's scene, 640x360, 16 spp, depth 50: the CPU restatement
+    against the digest of the buffer the reference's own code produced."""
+    import hashlib
+    scene, cam, _ = orc.model_scene(os.path.join(MODELS, "pawn.triangles"))
+    frame = orc.camera_frame(cam, 640 / 360, 640, 360)
+    frame.sample_count = 16
+    accum = scene.render(frame, threads=8)
+    assert hashlib.sha256(accum.tobytes()).digest() == golden["pawn640_accum16_sha"].tobytes()
+    assert (accum.reshape(-1, 4)[:, 3] == 16.0).all()
+
+
 @pytest.mark.parametrize("name,size", [("rook", (64, 48)), ("pawn", (64, 36))])
 def test_model_scene_render(orc, golden, name, size):
     scene, cam, aspect = orc.model_scene(os.path.join(MODELS, name + ".triangles"))
