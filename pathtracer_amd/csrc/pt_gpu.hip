@@ -447,9 +447,14 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
         all.max.x = pt::max_of(all.max.x, b.max.x); all.max.y = pt::max_of(all.max.y, b.max.y); all.max.z = pt::max_of(all.max.z, b.max.z);
     }
     const double extent[6] = {all.min.x, all.min.y, all.min.z, all.max.x, all.max.y, all.max.z};
-    for (double v : extent) {
-        if (!(std::fabs(v) <= MAX_COORD32)) return PT_OK;      // also false for NaN
+    auto in_range = [](const PtAabb& b) {                       // false for NaN too
+        return std::fabs(b.min.x) <= MAX_COORD32 && std::fabs(b.min.y) <= MAX_COORD32 && std::fabs(b.min.z) <= MAX_COORD32 &&
+               std::fabs(b.max.x) <= MAX_COORD32 && std::fabs(b.max.y) <= MAX_COORD32 && std::fabs(b.max.z) <= MAX_COORD32;
+    };
+    for (const PtAabb& b : own_boxes) {
+        if (!in_range(b)) return PT_OK;
     }
+    if (d.sphere_count == 1 && !in_range(pt::box_of(d.spheres[0]))) return PT_OK;    // the lone sphere's box is tested by the same kernel
 
     std::vector<PairNode> merged_pairs;
     const std::vector<PairNode>* pairs = &tri_pairs;

@@ -38,7 +38,7 @@ struct TreeRef {
 // distance; the exact f64 test of the leaf's own box decides (LeafBox).
 //
 // Conservative test: boxes are stored rounded outward; the lower plane is taken relative to
-// the origin rounded up and the upper plane relative to the origin rounded down, so before
+// a float at or above the origin and the upper plane relative to one at or below it, so before
 // rounding the f32 slab interval contains the exact one; the three roundings per product
 // (subtract, reciprocal, multiply: 3 * 2^-24 relative) are covered by widening the interval by
 // RHO = 2^-20 relative plus EPS32 absolute (denormal range).
@@ -65,19 +65,19 @@ constexpr double MAX_COORD32 = 1048576.0;        // |coordinate| <= 2^20 keeps e
 constexpr double MAX_INV32 = 1.2676506002282294e30;   // 2^100
 
 struct Ray32 {
-    float ohx, ohy, ohz;     // origin rounded up
-    float olx, oly, olz;     // origin rounded down
+    float ohx, ohy, ohz;     // a float at or above each origin coordinate
+    float olx, oly, olz;     // a float at or below it
     float ix, iy, iz;        // reciprocals, rounded to nearest
 };
 
-PT_DEV float next_up32(float f) {      // smallest float > f (finite f)
-    const uint32_t u = __float_as_uint(f);
-    if (f == 0.0f) return __uint_as_float(1u);
-    return __uint_as_float((u >> 31) ? u - 1u : u + 1u);
+// A float >= x and a float <= x for |x| <= 2^20: the nearest float moved outward by |f| * 2^-23, which
+// is at least one unit in its last place (so it passes x, at most half a unit away), plus 1e-37 for
+// the denormal range, where that product vanishes.
+PT_DEV void bracket32(double x, float& above, float& below) {
+    const float f = (float)x;
+    above = fmaf(fabsf(f), 1.1920928955078125e-07f, f) + 1.0e-37f;
+    below = fmaf(fabsf(f), -1.1920928955078125e-07f, f) - 1.0e-37f;
 }
-PT_DEV float next_down32(float f) { return -next_up32(-f); }
-PT_DEV float round_up32(double x) { const float f = (float)x; return ((double)f < x) ? next_up32(f) : f; }
-PT_DEV float round_down32(double x) { const float f = (float)x; return ((double)f > x) ? next_down32(f) : f; }
 
 // True if the ray may use the f32 inner nodes (otherwise it takes the exact traversal).
 PT_DEV bool ray32_allowed(const Ray& ray, D3 inv) {
@@ -85,9 +85,14 @@ PT_DEV bool ray32_allowed(const Ray& ray, D3 inv) {
            fabs(ray.o.x) <= MAX_COORD32 && fabs(ray.o.y) <= MAX_COORD32 && fabs(ray.o.z) <= MAX_COORD32;
 }
 PT_DEV Ray32 make_ray32(const Ray& ray, D3 inv) {
-    return Ray32{round_up32(ray.o.x), round_up32(ray.o.y), round_up32(ray.o.z),
-                 round_down32(ray.o.x), round_down32(ray.o.y), round_down32(ray.o.z),
-                 (float)inv.x, (float)inv.y, (float)inv.z};
+    Ray32 r;
+    bracket32(ray.o.x, r.ohx, r.olx);
+    bracket32(ray.o.y, r.ohy, r.oly);
+    bracket32(ray.o.z, r.ohz, r.olz);
+    r.ix = (float)inv.x;
+    r.iy = (float)inv.y;
+    r.iz = (float)inv.z;
+    return r;
 }
 // Upper bound, as a float, of the pruning distance.
 PT_DEV float cut32_of(double cut) { return (float)((cut + 1.0e-30) * (1.0 + 4.76837158203125e-07)); }

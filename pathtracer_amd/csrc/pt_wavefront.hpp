@@ -114,6 +114,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     D3 inv{0, 0, 1}, att{1.0f, 1.0f, 1.0f};
     Ray32 r32{0, 0, 0, 0, 0, 0, 1, 1, 1};
 
+    // The reference's box test (src/geometry.cpp:7-37).  Its min/max argument order matters only when a
+    // slab product is NaN, which needs an infinite reciprocal or a NaN in the ray or the box.  A scene
+    // that uses the single-precision hierarchy has finite boxes only (checked when it is built): there,
+    // when no active lane's ray has such a value, the hardware min/max give the same values with half
+    // the instructions.
+    auto box_test = [&](D3 origin, D3 reciprocal, const double* box, double& tmin, double& tmax) {
+        const bool plain = isfinite(reciprocal.x + reciprocal.y + reciprocal.z) && isfinite(origin.x + origin.y + origin.z);
+        if (NODE32 && __ballot(!plain) == 0ull) slab_finite(origin, reciprocal, box[0], box[1], box[2], box[3], box[4], box[5], tmin, tmax);
+        else slab_exact(origin, reciprocal, box, tmin, tmax);
+    };
+
     // Leaves the current node: takes the pending subtree on top of the stack, or ends the search.
     auto pop_once = [&]() {
         const int top = max(sp - 1, 0);
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // reciprocals) arrives here with a box it has tested itself.
                     const double* b = s.tri_boxes[best_i].box;
                     double tmin, tmax;
-                    slab_exact(ray.o, inv, b, tmin, tmax);
+                    box_test(ray.o, inv, b, tmin, tmax);
                     tie = tie | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((best_i & w.distrust_mask) == 0));
                 }
                 if (merged) {
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     if (hs.index >= 0) {
                         const double* b = s.tri_boxes[s.sphere_base + hs.index].box;
                         double tmin, tmax;
-                        slab_exact(ray.o, inv, b, tmin, tmax);
+                        box_test(ray.o, inv, b, tmin, tmax);
                         tie_s = tie_s | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((hs.index & w.distrust_mask) == 0));
                     }
                     tie = tie | tie_s;
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // one sphere: its node is the root and a leaf; the reference tests the box, then the sphere
                     // (src/path_tracing.cpp:113-127); min/max order matters only if a slab product is NaN
                     double tmin, tmax, d;
-                    slab_exact(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
+                    box_test(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
                     if (!(tmax < 0.0f || tmin > tmax) && hit_sphere(ray, s.spheres, d)) hs = Hit{0, d};
                 } else if (!merged || kind != RAY_FINITE) {
                     // spheres outside the search hierarchy, or a ray the hierarchy cannot take: the lane walks
