@@ -7,7 +7,7 @@
 //
 // Parity pin: every function here is checked bit-for-bit against the reference's
 // own sources compiled in place (oracle/_ref/libptref.so, see ref_harness.cpp) by
-// tests/test_oracle_vs_reference.py, and against the committed vectors in
+// tests/test_oracle.py, and against the committed vectors in
 // tests/golden/ that were produced by that build (oracle/gen_golden.py).
 //
 // Arithmetic rules that make the restatement exact:
@@ -492,6 +492,33 @@ unsigned orc_noise_1d(int x) { return hash1((u32)x); }
 unsigned orc_noise_3d(int x, int y, int z) { return hash3(x, y, z); }
 unsigned orc_random_number(unsigned seed) { return xorshift(seed); }
 double orc_real_from_rng(unsigned rng) { return unit_real(rng); }
+
+// Checks, for every r in [begin, end), that the GPU library's division-free form of real_from_rng
+// (pathtracer_amd/csrc/pt_device.hpp) gives the bits of the reference's r / UINT_MAX; returns the
+// number of values that differ.  std::fma is exact (one rounding) whether or not the CPU has the instruction.
+unsigned long long orc_check_fused_unit_real(unsigned long long begin, unsigned long long end, int threads) {
+    std::vector<std::thread> pool;
+    std::vector<unsigned long long> wrong(threads > 0 ? threads : 1, 0);
+    const int n = (int)wrong.size();
+    for (int t = 0; t < n; ++t) {
+        pool.emplace_back([&, t]() {
+            const unsigned long long lo = begin + (end - begin) * t / n, hi = begin + (end - begin) * (t + 1) / n;
+            unsigned long long bad = 0;
+            for (unsigned long long i = lo; i < hi; ++i) {
+                const u32 r = (u32)i;
+                const double d = (double)r;
+                const double fused = std::fma(d, 0x1p-32, d * (0x1p-64 + 0x1p-96));
+                const double divided = unit_real(r);
+                bad += std::memcmp(&fused, &divided, sizeof(double)) != 0;
+            }
+            wrong[t] = bad;
+        });
+    }
+    for (std::thread& th : pool) th.join();
+    unsigned long long total = 0;
+    for (unsigned long long w : wrong) total += w;
+    return total;
+}
 void orc_random_unit_vector(const double* seed, double* out) {
     const V3 r = random_direction(V3{seed[0], seed[1], seed[2]});
     out[0] = r.x; out[1] = r.y; out[2] = r.z;

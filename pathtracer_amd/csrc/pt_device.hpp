@@ -62,7 +62,14 @@ PT_DEV uint32_t xorshift(uint32_t s) {                 // random_number, :63-69
     s ^= (s << 5);
     return s;
 }
-PT_DEV double real_from_rng(uint32_t r) { return (double)r / 4294967295.0; }   // :30-32, UINT_MAX
+// real_from_rng, :30-32: r / UINT_MAX, correctly rounded.  r / (2^32 - 1) = r 2^-32 + r 2^-64 + r 2^-96 + ...;
+// the first term exactly plus the rounded next two, in one fused multiply-add, rounds to the same double
+// as the division for every one of the 2^32 values of r (checked exhaustively on the CPU by the tests),
+// in 3 instructions instead of the 13 of a double-precision division.
+PT_DEV double real_from_rng(uint32_t r) {
+    const double d = (double)r;
+    return __builtin_fma(d, 0x1p-32, d * (0x1p-64 + 0x1p-96));
+}
 // static_cast<int>(double) as x86-64 performs it (cvttsd2si): out-of-range and NaN give INT_MIN,
 // where the GPU's own conversion would saturate or give 0.
 PT_DEV int to_int_x86(double v) {

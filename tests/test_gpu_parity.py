@@ -51,6 +51,16 @@ def test_device_hashes(api, golden):
     assert same_bits(out[:, 1], golden["xorshift_real"])
 
 
+def test_device_real_from_rng_matches_the_division(api):
+    """The device's division-free real_from_rng on 4 M hashes (all bit patterns near the ends, powers
+    of two and their neighbours, a stride through the rest) against r / UINT_MAX computed here."""
+    seeds = np.concatenate([np.arange(0, 1 << 16), np.arange((1 << 32) - (1 << 16), 1 << 32),
+                            np.arange(0, 1 << 32, 1109)]).astype(np.uint32)
+    out = api.device_eval(abi.PT_EVAL_XORSHIFT_REAL, seeds)
+    r = out[:, 0].view(np.uint64).astype(np.uint32)
+    assert same_bits(out[:, 1], r.astype(np.float64) / 4294967295.0)
+
+
 def test_device_sqrt_and_divide_are_correctly_rounded(api):
     rng = np.random.default_rng(11)
     a = np.concatenate([rng.uniform(0, 4, 200000), 10.0 ** rng.uniform(-300, 300, 200000), [0.0, 1.0, 2.0, 4.0, 1e-310, np.inf]])

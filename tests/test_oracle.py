@@ -82,6 +82,16 @@ def test_reference_builtin_scene_render(orc, golden, name, index, size):
     assert same_bits(scene.render(frame), golden[f"{name}_accum4"])
 
 
+def test_division_free_real_from_rng_is_exact_for_every_input(orc):
+    """The GPU maps a 32-bit hash to [0, 1] with a multiply and a fused multiply-add instead of the
+    reference's division by UINT_MAX (src/rng.cpp:30-32); all 2^32 inputs must give the same double."""
+    import ctypes as C
+    check = orc.dll.orc_check_fused_unit_real
+    check.restype = C.c_ulonglong
+    check.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_int]
+    assert check(0, 1 << 32, 8) == 0
+
+
 def test_plumbing_configuration_in_full(orc, golden):
     """Single pawn model in the reference's scene, 640x360, 16 spp, depth 50: the CPU restatement
     against the digest of the buffer the reference's own code produced."""
