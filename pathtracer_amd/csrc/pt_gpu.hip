@@ -472,6 +472,7 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
     if (pairs->empty()) return PT_OK;
     QuadBuild quads;
     collapse_to_quads(*pairs, 0, 0, &quads);
+    if (quads.nodes.size() > (size_t(1) << 25)) return PT_OK;   // the kernel addresses a node by a 32-bit byte offset
     scene->tri_stack_need = quads.deepest_pending + 3;      // a visit writes up to three slots above the pending entries
     if (std::getenv("PT_VERBOSE") != nullptr) {
         std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", own_boxes.size(),

@@ -37,11 +37,16 @@ struct TreeRef {
 // as no subtree is skipped that holds a leaf the exact test would accept within the pruning
 // distance; the exact f64 test of the leaf's own box decides (LeafBox).
 //
-// Conservative test: boxes are stored rounded outward; the lower plane is taken relative to
-// a float at or above the origin and the upper plane relative to one at or below it, so before
-// rounding the f32 slab interval contains the exact one; the three roundings per product
-// (subtract, reciprocal, multiply: 3 * 2^-24 relative) are covered by widening the interval by
-// RHO = 2^-20 relative plus EPS32 absolute (denormal range).
+// Conservative test: boxes are stored rounded outward.  Per axis the entry distance is
+// (near plane - origin) * reciprocal = near plane * reciprocal - origin * reciprocal, and the f32 code
+// evaluates the right-hand form with one fused multiply-add: the product is exact inside it, and
+// `origin * reciprocal` (taken with the f32 reciprocal, so that the reciprocal's rounding is a
+// common factor of the whole difference and nothing cancels) enters as a float at or ABOVE its value
+// for entry distances and at or BELOW it for exit distances.  Before its single rounding the f32 slab
+// interval therefore contains the exact one scaled by (1 + e), |e| <= 2^-24; that factor and the
+// rounding of the fused operation are covered by widening the interval by RHO = 2^-20 relative
+// plus EPS32 absolute (denormal range).  Which plane of a box is the near one follows from the
+// reciprocal's sign, so it is chosen when the plane is loaded and costs no min/max.
 //
 // Four children per node: a node of the binary hierarchy with its children (and, while slots are
 // free, the largest grandchildren) pulled up.  plane[k] holds the k-th bound (min x, y, z, max x, y,
@@ -65,12 +70,13 @@ constexpr double MAX_COORD32 = 1048576.0;        // |coordinate| <= 2^20 keeps e
 constexpr double MAX_INV32 = 1.2676506002282294e30;   // 2^100
 
 struct Ray32 {
-    float ohx, ohy, ohz;     // a float at or above each origin coordinate
-    float olx, oly, olz;     // a float at or below it
+    float cnx, cny, cnz;     // a float at or above origin * reciprocal: taken off the near plane's product
+    float cfx, cfy, cfz;     // a float at or below it: taken off the far plane's product
     float ix, iy, iz;        // reciprocals, rounded to nearest
+    unsigned kx, ky, kz;     // bytes from a node's lower plane of the axis to its near plane: 48 if the reciprocal is negative
 };
 
-// A float >= x and a float <= x for |x| <= 2^20: the nearest float moved outward by |f| * 2^-23, which
+// A float >= x and a float <= x for |x| <= 2^121: the nearest float moved outward by |f| * 2^-23, which
 // is at least one unit in its last place (so it passes x, at most half a unit away), plus 1e-37 for
 // the denormal range, where that product vanishes.
 PT_DEV void bracket32(double x, float& above, float& below) {
@@ -86,12 +92,16 @@ PT_DEV bool ray32_allowed(const Ray& ray, D3 inv) {
 }
 PT_DEV Ray32 make_ray32(const Ray& ray, D3 inv) {
     Ray32 r;
-    bracket32(ray.o.x, r.ohx, r.olx);
-    bracket32(ray.o.y, r.ohy, r.oly);
-    bracket32(ray.o.z, r.ohz, r.olz);
     r.ix = (float)inv.x;
     r.iy = (float)inv.y;
     r.iz = (float)inv.z;
+    // |origin| <= 2^20 and |reciprocal| <= 2^100: the products (rounded once more, in f64) stay far inside the f32 range
+    bracket32(ray.o.x * (double)r.ix, r.cnx, r.cfx);
+    bracket32(ray.o.y * (double)r.iy, r.cny, r.cfy);
+    bracket32(ray.o.z * (double)r.iz, r.cnz, r.cfz);
+    r.kx = (inv.x < 0.0f) ? 48u : 0u;
+    r.ky = (inv.y < 0.0f) ? 48u : 0u;
+    r.kz = (inv.z < 0.0f) ? 48u : 0u;
     return r;
 }
 // Upper bound, as a float, of the pruning distance.
@@ -100,15 +110,31 @@ PT_DEV float cut32_of(double cut) { return (float)((cut + 1.0e-30) * (1.0 + 4.76
 // Conservative bounds of the four child boxes at once, on 4-wide vectors: `lower` <= exact entry
 // distance, `upper` >= exact exit distance.
 typedef float Float4 __attribute__((ext_vector_type(4)));
-PT_DEV Float4 min4(Float4 a, Float4 b) { return Float4{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w)}; }
-PT_DEV Float4 max4(Float4 a, Float4 b) { return Float4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
-PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ q, Float4& lower, Float4& upper) {
-    const Float4* plane = reinterpret_cast<const Float4*>(q->plane);
-    const Float4 x0 = (plane[0] - r.ohx) * r.ix, x1 = (plane[3] - r.olx) * r.ix;
-    const Float4 y0 = (plane[1] - r.ohy) * r.iy, y1 = (plane[4] - r.oly) * r.iy;
-    const Float4 z0 = (plane[2] - r.ohz) * r.iz, z1 = (plane[5] - r.olz) * r.iz;
-    const Float4 tmin = max4(min4(z0, z1), max4(min4(y0, y1), min4(x0, x1)));
-    const Float4 tmax = min4(max4(z0, z1), min4(max4(y0, y1), max4(x0, x1)));
+typedef int Int4 __attribute__((ext_vector_type(4)));
+PT_DEV Float4 fma4(Float4 p, float i, float c) { return Float4{fmaf(p.x, i, c), fmaf(p.y, i, c), fmaf(p.z, i, c), fmaf(p.w, i, c)}; }
+PT_DEV Float4 max4_3(Float4 a, Float4 b, Float4 c) {
+    return Float4{fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z), fmaxf(fmaxf(a.w, b.w), c.w)};
+}
+PT_DEV Float4 min4_3(Float4 a, Float4 b, Float4 c) {
+    return Float4{fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z), fminf(fminf(a.w, b.w), c.w)};
+}
+// Node `node` of `nodes`: every field is addressed as the array's base plus a 32-bit byte offset (the
+// host keeps the array below 4 GB), the form the hardware adds by itself.
+PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int node, Float4& lower, Float4& upper, Int4& children) {
+    const char* base = reinterpret_cast<const char*>(nodes);
+    const unsigned at = (unsigned)node << 7, at_upper = at + 48u;
+    auto field = [&](unsigned offset, int more) { return *reinterpret_cast<const Float4*>(base + (size_t)offset + more); };
+    // every load is issued before the first result is used
+    const Float4 px0 = field(at + r.kx, 0), px1 = field(at_upper - r.kx, 0);
+    const Float4 py0 = field(at + r.ky, 16), py1 = field(at_upper - r.ky, 16);
+    const Float4 pz0 = field(at + r.kz, 32), pz1 = field(at_upper - r.kz, 32);
+    children = *reinterpret_cast<const Int4*>(base + (size_t)at + 96);
+    const Float4 x0 = fma4(px0, r.ix, -r.cnx), x1 = fma4(px1, r.ix, -r.cfx);
+    const Float4 y0 = fma4(py0, r.iy, -r.cny), y1 = fma4(py1, r.iy, -r.cfy);
+    const Float4 z0 = fma4(pz0, r.iz, -r.cnz), z1 = fma4(pz1, r.iz, -r.cfz);
+    // an empty slot is NaN on every axis, so it stays NaN through max/min
+    const Float4 tmin = max4_3(x0, y0, z0);
+    const Float4 tmax = min4_3(x1, y1, z1);
     lower = Float4{fmaf(fabsf(tmin.x), -RHO32, tmin.x), fmaf(fabsf(tmin.y), -RHO32, tmin.y),
                    fmaf(fabsf(tmin.z), -RHO32, tmin.z), fmaf(fabsf(tmin.w), -RHO32, tmin.w)};
     upper = Float4{fmaf(fabsf(tmax.x), RHO32, tmax.x), fmaf(fabsf(tmax.y), RHO32, tmax.y),

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     Hit hs{-1, REAL_MAX};
     Ray ray{D3{0, 0, 0}, D3{0, 0, 1}};
     D3 inv{0, 0, 1}, att{1.0f, 1.0f, 1.0f};
-    Ray32 r32{0, 0, 0, 0, 0, 0, 1, 1, 1};
+    Ray32 r32{0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0};
 
     // The reference's box test (src/geometry.cpp:7-37).  Its min/max argument order matters only when a
     // slab product is NaN, which needs an infinite reciprocal or a NaN in the ray or the box.  A scene
@@ -364,10 +364,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // are kept (the launch sizes the stack for it), and every decision is a select.
             if (st == ST_NODE) {
                 if (NODE32) {
-                    const QuadNode32* q = s.tri_quads + cur;
-                    const int c0 = q->child[0], c1 = q->child[1], c2 = q->child[2], c3 = q->child[3];
                     Float4 low, up;
-                    slab32_quad(r32, q, low, up);
+                    Int4 children;
+                    slab32_quad(r32, s.tri_quads, cur, low, up, children);
+                    const int c0 = children.x, c1 = children.y, c2 = children.z, c3 = children.w;
                     // an empty slot holds NaN planes: every comparison below is false for it
                     const bool go0 = enter32(low.x, up.x, cut32), go1 = enter32(low.y, up.y, cut32);
                     const bool go2 = enter32(low.z, up.z, cut32), go3 = enter32(low.w, up.w, cut32);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         for (int i = 0; i < 4; ++i) {
                             double tmin, tmax;
                             slab_finite(ray.o, inv, e->box[i][0], e->box[i][1], e->box[i][2], e->box[i][3], e->box[i][4], e->box[i][5], tmin, tmax);
-                            const bool exact = (q->child[i] != 0) && !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
+                            const bool exact = (s.tri_quads[cur].child[i] != 0) && !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
                             unsafe = unsafe || (exact && !go[i]);
                         }
                         ws.unsafe_skips += __popcll(__ballot(unsafe));
