@@ -597,7 +597,7 @@ int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, 
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, BLOCK_THREADS, stack_bytes));
         return PT_OK;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream, dev, fp, wp, rgb, counter, stats);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream, TraceArgs{dev, fp, wp, rgb, counter, stats});
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }

@@ -111,7 +111,12 @@ PT_DEV float cut32_of(double cut) { return (float)((cut + 1.0e-30) * (1.0 + 4.76
 // distance, `upper` >= exact exit distance.
 typedef float Float4 __attribute__((ext_vector_type(4)));
 typedef int Int4 __attribute__((ext_vector_type(4)));
-PT_DEV Float4 fma4(Float4 p, float i, float c) { return Float4{fmaf(p.x, i, c), fmaf(p.y, i, c), fmaf(p.z, i, c), fmaf(p.w, i, c)}; }
+typedef float Float2 __attribute__((ext_vector_type(2)));
+PT_DEV Float4 fma4(Float4 p, float i, float c) {       // two packed fused multiply-adds
+    const Float2 lo = __builtin_elementwise_fma(Float2{p.x, p.y}, Float2{i, i}, Float2{c, c});
+    const Float2 hi = __builtin_elementwise_fma(Float2{p.z, p.w}, Float2{i, i}, Float2{c, c});
+    return Float4{lo.x, lo.y, hi.x, hi.y};
+}
 PT_DEV Float4 max4_3(Float4 a, Float4 b, Float4 c) {
     return Float4{fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z), fmaxf(fmaxf(a.w, b.w), c.w)};
 }

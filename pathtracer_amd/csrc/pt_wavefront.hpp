@@ -52,6 +52,26 @@ struct WorkParams {
 // chunk's sample group at pixel (j % 64) of the chunk's tile.
 PT_DEV long long rgb_index(long long chunk, int channel, int j) { return (chunk * CHUNK_PATHS + j) * 4 + channel; }
 
+// Everything the kernel is given, as one argument: the kernel-argument segment then holds exactly this
+// struct, and code that runs once in a while can fetch what it needs from there when it needs it.
+struct TraceArgs {
+    DeviceScene s;
+    FrameParams f;
+    WorkParams w;
+    double* rgb;
+    unsigned int* next_chunk;
+    unsigned long long* stats;
+};
+// The argument struct behind a pointer the compiler must treat as new at this point: what is read through
+// it is fetched here, by scalar loads, instead of being kept in scalar registers across the whole work
+// loop, where the node and leaf steps need those registers.
+typedef const __attribute__((address_space(4))) TraceArgs* ArgsInMemory;
+PT_DEV ArgsInMemory args_fetched_here() {
+    ArgsInMemory p = (ArgsInMemory)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4 };
 
 struct WaveStats {   // wave-uniform counters of a profiling build
@@ -77,10 +97,12 @@ struct WaveShared {
 #define PT_WAVES_PER_SIMD 3
 #endif
 template <int STATS, bool NODE32, bool MERGED>
-__global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_kernel(DeviceScene s, FrameParams f, WorkParams w,
-                                                                    double* __restrict__ rgb,
-                                                                    unsigned int* __restrict__ next_chunk,
-                                                                    unsigned long long* __restrict__ stats) {
+__global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_kernel(TraceArgs args) {
+    const DeviceScene& s = args.s;
+    const WorkParams& w = args.w;
+    double* const __restrict__ rgb = args.rgb;
+    unsigned int* const __restrict__ next_chunk = args.next_chunk;
+    unsigned long long* const __restrict__ stats = args.stats;
     __shared__ WaveShared sh;
     extern __shared__ int lane_stacks[];
     const int lane = threadIdx.x & 63;
@@ -146,6 +168,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             if (n_ready == 0) break;      // nothing in flight, nothing to shade, no work left
             if (STATS) { ++ws.shade_phases; ws.shade_lanes += n_ready; }
             if (STATS == 2) t0 = clock64();
+            const ArgsInMemory fetched = args_fetched_here();
+            const FrameParams& f = *(const FrameParams*)&fetched->f;      // camera and frame: used by this branch only
+            const DeviceScene& scene_for_shading = *(const DeviceScene*)&fetched->s;   // materials, normals, background
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
                 }
                 D3 gain;
-                const bool go_on = shade_vertex(s, ray, hs, ht, att, gain);
+                const bool go_on = shade_vertex(scene_for_shading, ray, hs, ht, att, gain);
                 ++bounce;
                 if (!go_on || bounce >= f.max_bounces) {
                     // every earlier vertex added +-0 (see the file header): colour = 0 + last term
