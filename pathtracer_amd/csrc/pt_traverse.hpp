@@ -140,15 +140,17 @@ PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int
     // an empty slot is NaN on every axis, so it stays NaN through max/min
     const Float4 tmin = max4_3(x0, y0, z0);
     const Float4 tmax = min4_3(x1, y1, z1);
-    lower = Float4{fmaf(fabsf(tmin.x), -RHO32, tmin.x), fmaf(fabsf(tmin.y), -RHO32, tmin.y),
-                   fmaf(fabsf(tmin.z), -RHO32, tmin.z), fmaf(fabsf(tmin.w), -RHO32, tmin.w)};
-    upper = Float4{fmaf(fabsf(tmax.x), RHO32, tmax.x), fmaf(fabsf(tmax.y), RHO32, tmax.y),
-                   fmaf(fabsf(tmax.z), RHO32, tmax.z), fmaf(fabsf(tmax.w), RHO32, tmax.w)};
+    // Widening.  A non-negative entry distance is lowered by RHO relative; a negative one passes both of
+    // its comparisons whatever its size, so it needs none.  The exit distance matters only when the exact
+    // one is >= 0, and then the f32 one is >= 0 too, up to an error in the denormal range: it is raised by
+    // RHO relative, and EPS32 is added once here instead of in every comparison (`upper` includes it).
+    lower = tmin * (1.0f - RHO32);
+    upper = fma4(tmax, 1.0f + RHO32, EPS32);
 }
 // May the child be entered?  True for every box the exact test accepts within `cut`; false for NaN
-// bounds (empty slots).
+// bounds (empty slots).  `upper` is slab32_quad's: EPS32 above the widened exit distance.
 PT_DEV bool enter32(float lower, float upper, float cut32) {
-    return (upper >= -EPS32) & (lower - upper <= EPS32) & (lower <= cut32);
+    return (upper >= 0.0f) & (lower <= upper) & (lower <= cut32);
 }
 // Puts the pair with the smaller key first.
 PT_DEV void order2(float& ka, int& ra, float& kb, int& rb) {

@@ -100,8 +100,6 @@ template <int STATS, bool NODE32, bool MERGED>
 __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_kernel(TraceArgs args) {
     const DeviceScene& s = args.s;
     const WorkParams& w = args.w;
-    double* const __restrict__ rgb = args.rgb;
-    unsigned int* const __restrict__ next_chunk = args.next_chunk;
     unsigned long long* const __restrict__ stats = args.stats;
     __shared__ WaveShared sh;
     extern __shared__ int lane_stacks[];
@@ -210,7 +208,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // every earlier vertex added +-0 (see the file header): colour = 0 + last term
                     const long long c = slot / CHUNK_PATHS;
                     const int j = (int)(slot % CHUNK_PATHS);
-                    double* record = rgb + rgb_index(c, 0, j);
+                    double* record = fetched->rgb + rgb_index(c, 0, j);
                     record[0] = 0.0f + gain.x;
                     record[1] = 0.0f + gain.y;
                     record[2] = 0.0f + gain.z;
@@ -224,6 +222,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- hand new paths to idle lanes
             // Camera rays are made 64 at a time by the whole wave (all lanes busy, whatever their own path is
             // doing) and parked in LDS; an idle lane then only picks one up.
+            const WorkParams& cold = *(const WorkParams*)&fetched->w;       // how chunks are dealt: read when a chunk is drawn
             for (;;) {
                 const unsigned long long m_need = __ballot(st == ST_NEED);
                 if (m_need == 0ull) break;
@@ -233,14 +232,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         // Chunks are dealt per band: tile row r belongs to band r % bands and each band has its own
                         // counter.  A wave draws from the band of its XCD first, so the waves sharing an L2 work on
                         // the same rows of tiles; when that band is empty it helps the next one.
-                        const unsigned int per_row = (unsigned int)w.tiles_x * (unsigned int)w.groups_per_tile;
+                        const unsigned int per_row = (unsigned int)cold.tiles_x * (unsigned int)cold.groups_per_tile;
                         int band = -1;
                         unsigned int c = 0;
-                        while (bands_tried < w.bands) {
-                            const int b = (home_band + bands_tried) % w.bands;
-                            const unsigned int rows_in_band = (unsigned int)((w.tile_rows - b + w.bands - 1) / w.bands);
+                        while (bands_tried < cold.bands) {
+                            const int b = (home_band + bands_tried) % cold.bands;
+                            const unsigned int rows_in_band = (unsigned int)((cold.tile_rows - b + cold.bands - 1) / cold.bands);
                             unsigned int v = 0;
-                            if (lane == 0) v = atomicAdd(next_chunk + 16 * b, 1u);
+                            if (lane == 0) v = atomicAdd(fetched->next_chunk + 16 * b, 1u);
                             v = __builtin_amdgcn_readfirstlane(v);
                             if (v < rows_in_band * per_row) { band = b; c = v; break; }
                             ++bands_tried;                       // that band is finished for good
@@ -248,10 +247,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         if (band < 0) { work_left = false; break; }
                         const unsigned int band_row = c / per_row;
                         const unsigned int rest = c - band_row * per_row;
-                        const unsigned int tile_col = rest / (unsigned int)w.groups_per_tile;
-                        const int group = (int)(rest - tile_col * (unsigned int)w.groups_per_tile);
-                        const unsigned int tile_row = band_row * (unsigned int)w.bands + (unsigned int)band;
-                        chunk = (tile_row * (unsigned int)w.tiles_x + tile_col) * (unsigned int)w.groups_per_tile + (unsigned int)group;
+                        const unsigned int tile_col = rest / (unsigned int)cold.groups_per_tile;
+                        const int group = (int)(rest - tile_col * (unsigned int)cold.groups_per_tile);
+                        const unsigned int tile_row = band_row * (unsigned int)cold.bands + (unsigned int)band;
+                        chunk = (tile_row * (unsigned int)cold.tiles_x + tile_col) * (unsigned int)cold.groups_per_tile + (unsigned int)group;
                         chunk_next = 0;
                         chunk_col0 = (int)tile_col * 8;
                         chunk_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
