@@ -473,7 +473,7 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
     QuadBuild quads;
     collapse_to_quads(*pairs, 0, 0, &quads);
     if (quads.nodes.size() > (size_t(1) << 25)) return PT_OK;   // the kernel addresses a node by a 32-bit byte offset
-    scene->tri_stack_need = quads.deepest_pending + 3;      // a visit writes up to three slots above the pending entries
+    scene->tri_stack_need = quads.deepest_pending + 4;      // a visit writes four slots above the pending entries
     if (std::getenv("PT_VERBOSE") != nullptr) {
         std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", own_boxes.size(),
                      merge ? " (triangles and spheres in one hierarchy)" : "", pairs->size(), quads.nodes.size(), scene->tri_stack_need);
@@ -641,7 +641,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     // per-lane stack slots: the triangle search's need, and the sphere tree's when it is walked in place
     // (a lane of the 4-wide search that would outgrow its slots falls back to the exhaustive traversal, so
     // any number >= 3 is correct there; the binary search and the sphere tree need their full height)
-    const int quad_slots = std::max(3, t.stack_slots > 0 ? std::min(t.stack_slots, scene->tri_stack_need) : scene->tri_stack_need);
+    const int quad_slots = std::max(4, t.stack_slots > 0 ? std::min(t.stack_slots, scene->tri_stack_need) : scene->tri_stack_need);
     const int stack_slots = std::min(std::max(std::max(node32 ? quad_slots : scene->tri_height, scene->sph_height), 4),
                                      static_cast<int>(MAX_WF_STACK_SLOTS));
     const size_t stack_bytes = static_cast<size_t>(stack_slots) * BLOCK_THREADS * sizeof(int);

@@ -152,17 +152,6 @@ PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int
 PT_DEV bool enter32(float lower, float upper, float cut32) {
     return (upper >= 0.0f) & (lower <= upper) & (lower <= cut32);
 }
-// Puts the pair with the smaller key first.
-PT_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
-    const bool swap = kb < ka;
-    const float k = swap ? kb : ka;
-    const int r = swap ? rb : ra;
-    kb = swap ? ka : kb;
-    rb = swap ? ra : rb;
-    ka = k;
-    ra = r;
-}
-
 struct DeviceScene {
     TreeRef tri_tree;
     const TriRecord* tris;

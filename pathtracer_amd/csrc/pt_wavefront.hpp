@@ -384,8 +384,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS) { ++ws.node_phases; ws.node_lanes += __popcll(m_node); }
             if (STATS == 2) t0 = clock64();
-            // Straight-line code: far children are written above the top of the stack whether or not they
-            // are kept (the launch sizes the stack for it), and every decision is a select.
+            // Straight-line code: all four children are written to the stack, skipped ones above its new top
+            // (the launch sizes the stack for it), and every decision is a select.
             if (st == ST_NODE) {
                 if (NODE32) {
                     Float4 low, up;
@@ -407,34 +407,30 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         }
                         ws.unsafe_skips += __popcll(__ballot(unsafe));
                     }
-                    // children in order of entry distance, skipped ones last
+                    // Every child is written to the stack at the place its entry distance gives it, the nearest
+                    // on top, skipped ones above the new top (where nothing is read); then the top is taken.
+                    // rank = how many children come before this one (ties: lower slot first).  Entry distances are
+                    // finite (finite planes and reciprocals), so every entered child ranks before every skipped one.
                     const float far = __builtin_inff();
-                    float k0 = go0 ? low.x : far, k1 = go1 ? low.y : far, k2 = go2 ? low.z : far, k3 = go3 ? low.w : far;
-                    int r0 = c0, r1 = c1, r2 = c2, r3 = c3;
-                    order2(k0, r0, k1, r1);
-                    order2(k2, r2, k3, r3);
-                    order2(k0, r0, k2, r2);
-                    order2(k1, r1, k3, r3);
-                    order2(k1, r1, k2, r2);
+                    const float k0 = go0 ? low.x : far, k1 = go1 ? low.y : far, k2 = go2 ? low.z : far, k3 = go3 ? low.w : far;
+                    const int b01 = k1 < k0, b02 = k2 < k0, b03 = k3 < k0, b12 = k2 < k1, b13 = k3 < k1, b23 = k3 < k2;
+                    const int rank0 = b01 + b02 + b03, rank1 = 1 - b01 + b12 + b13, rank2 = 2 - b02 - b12 + b23, rank3 = 3 - b03 - b13 - b23;
                     const int count = (go0 ? 1 : 0) + (go1 ? 1 : 0) + (go2 ? 1 : 0) + (go3 ? 1 : 0);
-                    // kept child i (1 <= i < count) goes to slot sp + count-1-i, the nearest of them on top; the
-                    // others land above the new top and are never read
-                    const int keep = max(count - 1, 0);
-                    stack_ref[(sp + ((1 < count) ? count - 2 : 0)) * BLOCK_THREADS] = r1;
-                    stack_ref[(sp + ((2 < count) ? count - 3 : 1)) * BLOCK_THREADS] = r2;
-                    stack_ref[(sp + ((3 < count) ? 0 : 2)) * BLOCK_THREADS] = r3;
-                    sp += keep;
-                    const bool stuck = (count == 0);
+                    const int last = count - 1;
+                    stack_ref[(sp + ((last - rank0) & 3)) * BLOCK_THREADS] = c0;
+                    stack_ref[(sp + ((last - rank1) & 3)) * BLOCK_THREADS] = c1;
+                    stack_ref[(sp + ((last - rank2) & 3)) * BLOCK_THREADS] = c2;
+                    stack_ref[(sp + ((last - rank3) & 3)) * BLOCK_THREADS] = c3;
+                    sp += count;
                     const int top = max(sp - 1, 0);
-                    const int pending = stack_ref[top * BLOCK_THREADS];
-                    const int next = stuck ? pending : r0;
+                    const int next = stack_ref[top * BLOCK_THREADS];
                     // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
-                    // waves per CU).  A lane about to outgrow its stack gives up the ordered search and is
-                    // resolved like a tie, by the exhaustive traversal, when it is shaded.
+                    // waves per CU).  A lane whose next visit could outgrow its stack gives up the ordered search
+                    // and is resolved like a tie, by the exhaustive traversal, when it is shaded.
                     const bool overflow = sp + 3 > w.stack_slots;
                     tie = tie | overflow;
-                    st = ((stuck && sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
-                    sp = stuck ? top : sp;
+                    st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
+                    sp = top;
                     cur = next;
                 } else {
                     const PairNode* p = s.tri_tree.pairs + cur;
