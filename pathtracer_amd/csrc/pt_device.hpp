@@ -117,21 +117,25 @@ PT_DEV void slab_finite(D3 o, D3 inv, double bx0, double by0, double bz0, double
     tmax = fmin(fmax(z0, z1), fmin(fmax(y0, y1), fmax(x0, x1)));
 }
 
-// Triangle record in HBM, 128 B: everything of intersect(ray, triangle) (:106-133) and
-// unit_normal (:84-90) that does not depend on the ray, precomputed on the host with the
-// same operations: a, ab = b-a, ac = c-a, n = ab^ac, nn = n.n, un = normalise(n).
+// Triangle record in HBM, 128 B: what intersect(ray, triangle) (:106-133) and unit_normal (:84-90)
+// need that does not depend on the ray, precomputed on the host with the same operations:
+// a, ab = b-a, ac = c-a, nn = n.n and un = normalise(n) for n = ab^ac.  n itself is formed again on
+// the device (nine operations, the same as on the host): the test then reads 80 bytes, five 16-byte
+// loads, instead of seven, and the load path, not arithmetic, is what the kernel runs out of first.
 struct TriRecord {
-    double a[3], ab[3], ac[3], n[3], nn, un[3];
+    double a[3], ab[3], ac[3], nn, un[3];
+    int32_t material;
+    int32_t pad_[5];
 };
 static_assert(sizeof(TriRecord) == 128, "TriRecord is one 128-byte line");
 
-// `Record` is any struct with the fields a, ab, ac, n (double[3]) and nn.
+// `Record` is any struct with the fields a, ab, ac (double[3]) and nn.
 template <class Record>
 PT_DEV bool hit_triangle(const Ray& ray, const Record* __restrict__ t, double& distance) {
     const D3 a{t->a[0], t->a[1], t->a[2]};
     const D3 ab{t->ab[0], t->ab[1], t->ab[2]};
     const D3 ac{t->ac[0], t->ac[1], t->ac[2]};
-    const D3 n{t->n[0], t->n[1], t->n[2]};
+    const D3 n = cross3(ab, ac);
     const double nn = t->nn;
     const double dn = dot3(ray.d, n);
     const bool parallel = fabs(dn) < 1.0e-6f;

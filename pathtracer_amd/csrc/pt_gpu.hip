@@ -167,7 +167,6 @@ __global__ void eval_kernel(int op, const void* __restrict__ in, long long n, vo
         t.a[0] = a.x; t.a[1] = a.y; t.a[2] = a.z;
         t.ab[0] = ab.x; t.ab[1] = ab.y; t.ab[2] = ab.z;
         t.ac[0] = ac.x; t.ac[1] = ac.y; t.ac[2] = ac.z;
-        t.n[0] = nrm.x; t.n[1] = nrm.y; t.n[2] = nrm.z;
         t.nn = dot3(nrm, nrm);
         double d;
         const bool ok = hit_triangle(Ray{D3{r[0], r[1], r[2]}, D3{r[3], r[4], r[5]}}, &t, d);
@@ -283,7 +282,7 @@ D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
 struct PtScene {
     int device = 0;
     DeviceScene dev{};
-    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_material, tri_quads, tri_quad_boxes, tri_leaf_boxes;
+    DeviceBuffer tri_pairs, tri_ref_nodes, tri_records, tri_quads, tri_quad_boxes, tri_leaf_boxes;
     int tri_height = 0, sph_height = 0;
     int tri_stack_need = 1;             // slots of the wavefront kernel's stack a search of the 4-wide hierarchy can touch
     DeviceBuffer sph_pairs, sph_ref_nodes, spheres, sph_material, materials;
@@ -757,16 +756,14 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
             r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
             r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
             r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
-            r.n[0] = n.x; r.n[1] = n.y; r.n[2] = n.z;
             r.nn = nn;
             r.un[0] = un.x; r.un[1] = un.y; r.un[2] = un.z;
+            r.material = d->triangle_material_indices[i];
+            for (int32_t& unused : r.pad_) unused = 0;
         }
         rc = upload(scene->tri_records, records.data(), records.size() * sizeof(TriRecord));
         if (rc != PT_OK) return rc;
-        rc = upload(scene->tri_material, d->triangle_material_indices, sizeof(int32_t) * d->triangle_count);
-        if (rc != PT_OK) return rc;
         scene->dev.tris = scene->tri_records.as<TriRecord>();
-        scene->dev.tri_material = scene->tri_material.as<int32_t>();
     }
     if (d->sphere_count > 0) {
         rc = build_tree(d->sphere_bvh, d->sphere_bvh_node_count, d->sphere_count, "sphere", scene->sph_pairs, scene->sph_ref_nodes,

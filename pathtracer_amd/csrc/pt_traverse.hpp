@@ -155,7 +155,6 @@ PT_DEV bool enter32(float lower, float upper, float cut32) {
 struct DeviceScene {
     TreeRef tri_tree;
     const TriRecord* tris;
-    const int32_t* tri_material;
     // The wavefront kernel's search hierarchy: 4-wide single-precision nodes over the triangles and, when
     // the scene has more than one sphere, over the spheres too (one search finds both nearest hits).
     // Primitive p of it is triangle p if p < sphere_base, else sphere p - sphere_base.
@@ -372,7 +371,7 @@ PT_DEV bool shade_vertex(const DeviceScene& s, Ray& ray, const Hit& hs, const Hi
             const TriRecord* t = s.tris + ht.index;
             p = add3(ray.o, scale3(ht.distance, ray.d));
             n = D3{t->un[0], t->un[1], t->un[2]};
-            material_index = s.tri_material[ht.index];
+            material_index = t->material;
         }
         const Mat m = load_material(s.materials + material_index);
         gain = D3{0.0f, 0.0f, 0.0f};                                       // get_emission, src/material.cpp:64-81

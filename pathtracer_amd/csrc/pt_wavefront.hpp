@@ -158,7 +158,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         const unsigned long long m_node = __ballot(st == ST_NODE);
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
         const bool paths_left = work_left || pool_taken < 64;
-        const unsigned long long m_ready = __ballot(st == ST_SHADE || (st == ST_NEED && paths_left));
+        // no lane is in ST_NEWRAY here (the set-up below resolves it at once): whoever is in none of the three is idle
+        const unsigned long long m_shade = __ballot(st == ST_SHADE);
+        const unsigned long long m_ready = paths_left ? ~(m_node | m_leaf) : m_shade;
         const int n_ready = __popcll(m_ready);
         if (STATS) ++ws.loops;
 
