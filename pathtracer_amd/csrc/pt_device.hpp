@@ -122,7 +122,7 @@ PT_DEV void slab_finite(D3 o, D3 inv, double bx0, double by0, double bz0, double
 // a, ab = b-a, ac = c-a, nn = n.n and un = normalise(n) for n = ab^ac.  n itself is formed again on
 // the device (nine operations, the same as on the host): the test then reads 80 bytes, five 16-byte
 // loads, instead of seven, and the load path, not arithmetic, is what the kernel runs out of first.
-struct TriRecord {
+struct alignas(128) TriRecord {
     double a[3], ab[3], ac[3], nn, un[3];
     int32_t material;
     int32_t pad_[5];

@@ -51,7 +51,7 @@ struct TreeRef {
 // Four children per node: a node of the binary hierarchy with its children (and, while slots are
 // free, the largest grandchildren) pulled up.  plane[k] holds the k-th bound (min x, y, z, max x, y,
 // z) of the four child boxes side by side; an empty slot holds NaN and is never entered.
-struct QuadNode32 {
+struct alignas(128) QuadNode32 {
     float plane[6][4];
     int32_t child[4];      // >= 0: quad index, < 0: ~primitive
     int32_t pad_[4];
@@ -62,7 +62,14 @@ struct QuadBoxes64 { double box[4][6]; };   // the exact child boxes, read only 
 // A leaf's own box exactly as the reference's BVH stores it: the reference tests it before the
 // triangle (src/path_tracing.cpp:113-127).  The wavefront kernel tests the triangle alone and then
 // checks the box of the one triangle that won, when the path is shaded.
-struct LeafBox { double box[6]; };
+struct alignas(16) LeafBox { double box[6]; };
+// The 48 bytes as three aligned 16-byte loads.
+typedef double Double2 __attribute__((ext_vector_type(2)));
+PT_DEV LeafBox fetch_leaf_box(const LeafBox* __restrict__ b) {
+    const Double2* v = reinterpret_cast<const Double2*>(b);
+    const Double2 lo = v[0], mid = v[1], hi = v[2];
+    return LeafBox{{lo.x, lo.y, mid.x, mid.y, hi.x, hi.y}};
+}
 
 constexpr float RHO32 = 9.5367431640625e-07f;    // 2^-20
 constexpr float EPS32 = 1.0e-30f;

@@ -180,9 +180,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // If the winner's box fails the exact test, some other triangle (or none) is the answer: the
                     // exhaustive traversal finds it.  A ray that traversal has handled already (infinite
                     // reciprocals) arrives here with a box it has tested itself.
-                    const double* b = s.tri_boxes[best_i].box;
+                    const LeafBox own = fetch_leaf_box(s.tri_boxes + best_i);
                     double tmin, tmax;
-                    box_test(ray.o, inv, b, tmin, tmax);
+                    box_test(ray.o, inv, own.box, tmin, tmax);
                     tie = tie | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((best_i & w.distrust_mask) == 0));
                 }
                 if (merged) {
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // search was pruned with the other's hits, so a doubt about one sends both to the
                     // exhaustive traversals.
                     if (hs.index >= 0) {
-                        const double* b = s.tri_boxes[s.sphere_base + hs.index].box;
+                        const LeafBox own = fetch_leaf_box(s.tri_boxes + s.sphere_base + hs.index);
                         double tmin, tmax;
-                        box_test(ray.o, inv, b, tmin, tmax);
+                        box_test(ray.o, inv, own.box, tmin, tmax);
                         tie_s = tie_s | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((hs.index & w.distrust_mask) == 0));
                     }
                     tie = tie | tie_s;
