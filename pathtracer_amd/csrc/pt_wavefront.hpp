@@ -154,6 +154,55 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         cur = pending;
     };
 
+    // One visit of a four-wide node by the lanes that are active here: four conservative box tests, the
+    // entered children pushed nearest on top, the top taken as the lane's next stop.
+    auto quad_step = [&](const int node) {
+        Float4 low, up;
+        Int4 children;
+        slab32_quad(r32, s.tri_quads, node, low, up, children);
+        const int c0 = children.x, c1 = children.y, c2 = children.z, c3 = children.w;
+        // an empty slot holds NaN planes: every comparison below is false for it
+        const bool go0 = enter32(low.x, up.x, cut32), go1 = enter32(low.y, up.y, cut32);
+        const bool go2 = enter32(low.z, up.z, cut32), go3 = enter32(low.w, up.w, cut32);
+        if (STATS == 1) {
+            const QuadBoxes64* e = s.tri_quad_boxes + node;
+            const bool go[4] = {go0, go1, go2, go3};
+            bool unsafe = false;
+            for (int i = 0; i < 4; ++i) {
+                double tmin, tmax;
+                slab_finite(ray.o, inv, e->box[i][0], e->box[i][1], e->box[i][2], e->box[i][3], e->box[i][4], e->box[i][5], tmin, tmax);
+                const bool exact = (s.tri_quads[node].child[i] != 0) && !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
+                unsafe = unsafe || (exact && !go[i]);
+            }
+            ws.unsafe_skips += __popcll(__ballot(unsafe));
+        }
+        // Every child is written to the stack at the place its entry distance gives it, the nearest
+        // on top, skipped ones above the new top (where nothing is read); then the top is taken.
+        // rank = how many children come before this one (ties: lower slot first).  Entry distances are
+        // finite (finite planes and reciprocals), so every entered child ranks before every skipped one.
+        const float far = __builtin_inff();
+        const float k0 = go0 ? low.x : far, k1 = go1 ? low.y : far, k2 = go2 ? low.z : far, k3 = go3 ? low.w : far;
+        const int b01 = k1 < k0, b02 = k2 < k0, b03 = k3 < k0, b12 = k2 < k1, b13 = k3 < k1, b23 = k3 < k2;
+        const int rank0 = b01 + b02 + b03, rank1 = 1 - b01 + b12 + b13, rank2 = 2 - b02 - b12 + b23, rank3 = 3 - b03 - b13 - b23;
+        const int count = (go0 ? 1 : 0) + (go1 ? 1 : 0) + (go2 ? 1 : 0) + (go3 ? 1 : 0);
+        const int last = count - 1;
+        stack_ref[(sp + ((last - rank0) & 3)) * BLOCK_THREADS] = c0;
+        stack_ref[(sp + ((last - rank1) & 3)) * BLOCK_THREADS] = c1;
+        stack_ref[(sp + ((last - rank2) & 3)) * BLOCK_THREADS] = c2;
+        stack_ref[(sp + ((last - rank3) & 3)) * BLOCK_THREADS] = c3;
+        sp += count;
+        const int top = max(sp - 1, 0);
+        const int next = stack_ref[top * BLOCK_THREADS];
+        // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
+        // waves per CU).  A lane whose next visit could outgrow its stack gives up the ordered search
+        // and is resolved like a tie, by the exhaustive traversal, when it is shaded.
+        const bool overflow = sp + 3 > w.stack_slots;
+        tie = tie | overflow;
+        st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
+        sp = top;
+        cur = next;
+    };
+
     for (;;) {
         const unsigned long long m_node = __ballot(st == ST_NODE);
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
@@ -321,15 +370,20 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                 } else if (kind == RAY_FINITE && (NODE32 ? s.search_count : s.tri_tree.count) > 0) {
                     // a triangle beyond the sphere hit cannot win (:183): the search may stop there
                     cut = prune_cut(hs.distance);
-                    double tmin, tmax;
-                    const double* rb = NODE32 ? s.search_box : s.tri_tree.root_box;
-                    slab_finite(ray.o, inv, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], tmin, tmax);
-                    if (!(tmax < 0.0f || tmin > tmax || tmin > cut)) {
-                        cur = NODE32 ? s.search_root : s.tri_tree.root;
-                        st = (cur < 0) ? ST_LEAF : ST_NODE;
-                        if (NODE32) {
-                            r32 = make_ray32(ray, inv);
-                            cut32 = cut32_of(cut);
+                    if (NODE32) {
+                        // Every new ray starts at the same node, so it is visited here and now: the lanes all read
+                        // the same 128 bytes (one access per load instead of one per lane), and the search needs
+                        // one node phase less.  The hierarchy's own box is not tested: its children's are.
+                        r32 = make_ray32(ray, inv);
+                        cut32 = cut32_of(cut);
+                        quad_step(0);
+                    } else {
+                        double tmin, tmax;
+                        const double* rb = s.tri_tree.root_box;
+                        slab_finite(ray.o, inv, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], tmin, tmax);
+                        if (!(tmax < 0.0f || tmin > tmax || tmin > cut)) {
+                            cur = s.tri_tree.root;
+                            st = (cur < 0) ? ST_LEAF : ST_NODE;
                         }
                     }
                 }
@@ -390,50 +444,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // (the launch sizes the stack for it), and every decision is a select.
             if (st == ST_NODE) {
                 if (NODE32) {
-                    Float4 low, up;
-                    Int4 children;
-                    slab32_quad(r32, s.tri_quads, cur, low, up, children);
-                    const int c0 = children.x, c1 = children.y, c2 = children.z, c3 = children.w;
-                    // an empty slot holds NaN planes: every comparison below is false for it
-                    const bool go0 = enter32(low.x, up.x, cut32), go1 = enter32(low.y, up.y, cut32);
-                    const bool go2 = enter32(low.z, up.z, cut32), go3 = enter32(low.w, up.w, cut32);
-                    if (STATS == 1) {
-                        const QuadBoxes64* e = s.tri_quad_boxes + cur;
-                        const bool go[4] = {go0, go1, go2, go3};
-                        bool unsafe = false;
-                        for (int i = 0; i < 4; ++i) {
-                            double tmin, tmax;
-                            slab_finite(ray.o, inv, e->box[i][0], e->box[i][1], e->box[i][2], e->box[i][3], e->box[i][4], e->box[i][5], tmin, tmax);
-                            const bool exact = (s.tri_quads[cur].child[i] != 0) && !(tmax < 0.0f || tmin > tmax) && !(tmin > cut);
-                            unsafe = unsafe || (exact && !go[i]);
-                        }
-                        ws.unsafe_skips += __popcll(__ballot(unsafe));
-                    }
-                    // Every child is written to the stack at the place its entry distance gives it, the nearest
-                    // on top, skipped ones above the new top (where nothing is read); then the top is taken.
-                    // rank = how many children come before this one (ties: lower slot first).  Entry distances are
-                    // finite (finite planes and reciprocals), so every entered child ranks before every skipped one.
-                    const float far = __builtin_inff();
-                    const float k0 = go0 ? low.x : far, k1 = go1 ? low.y : far, k2 = go2 ? low.z : far, k3 = go3 ? low.w : far;
-                    const int b01 = k1 < k0, b02 = k2 < k0, b03 = k3 < k0, b12 = k2 < k1, b13 = k3 < k1, b23 = k3 < k2;
-                    const int rank0 = b01 + b02 + b03, rank1 = 1 - b01 + b12 + b13, rank2 = 2 - b02 - b12 + b23, rank3 = 3 - b03 - b13 - b23;
-                    const int count = (go0 ? 1 : 0) + (go1 ? 1 : 0) + (go2 ? 1 : 0) + (go3 ? 1 : 0);
-                    const int last = count - 1;
-                    stack_ref[(sp + ((last - rank0) & 3)) * BLOCK_THREADS] = c0;
-                    stack_ref[(sp + ((last - rank1) & 3)) * BLOCK_THREADS] = c1;
-                    stack_ref[(sp + ((last - rank2) & 3)) * BLOCK_THREADS] = c2;
-                    stack_ref[(sp + ((last - rank3) & 3)) * BLOCK_THREADS] = c3;
-                    sp += count;
-                    const int top = max(sp - 1, 0);
-                    const int next = stack_ref[top * BLOCK_THREADS];
-                    // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
-                    // waves per CU).  A lane whose next visit could outgrow its stack gives up the ordered search
-                    // and is resolved like a tie, by the exhaustive traversal, when it is shaded.
-                    const bool overflow = sp + 3 > w.stack_slots;
-                    tie = tie | overflow;
-                    st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
-                    sp = top;
-                    cur = next;
+                    quad_step(cur);
                 } else {
                     const PairNode* p = s.tri_tree.pairs + cur;
                     const int lref = p->left, rref = p->right;
