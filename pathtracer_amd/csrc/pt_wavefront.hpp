@@ -91,8 +91,8 @@ struct WaveShared {
 // counters and shader-clock time per section (no cross-check, so the times are the product's).
 // MERGED (with NODE32 only): the hierarchy holds the spheres as well as the triangles.
 // NODE32: inner nodes are the 128-byte single-precision nodes with four children (conservative
-// test, exact test repeated at the leaf); otherwise the 128-byte double-precision pairs, whose
-// test is the reference's own.
+// test; the exact test of the winning primitive's own box is made before the path is shaded);
+// otherwise the 128-byte double-precision pairs, whose test is the reference's own.
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
