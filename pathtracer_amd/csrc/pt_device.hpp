@@ -135,8 +135,8 @@ PT_DEV bool hit_triangle(const Ray& ray, const Record* __restrict__ t, double& d
     const D3 a{t->a[0], t->a[1], t->a[2]};
     const D3 ab{t->ab[0], t->ab[1], t->ab[2]};
     const D3 ac{t->ac[0], t->ac[1], t->ac[2]};
-    const D3 n = cross3(ab, ac);
     const double nn = t->nn;
+    const D3 n = cross3(ab, ac);
     const double dn = dot3(ray.d, n);
     const bool parallel = fabs(dn) < 1.0e-6f;
     const double dist = dot3(sub3(a, ray.o), n) / dn;

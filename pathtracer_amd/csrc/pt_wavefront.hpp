@@ -260,10 +260,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     const long long c = slot / CHUNK_PATHS;
                     const int j = (int)(slot % CHUNK_PATHS);
                     double* record = fetched->rgb + rgb_index(c, 0, j);
-                    record[0] = 0.0f + gain.x;
-                    record[1] = 0.0f + gain.y;
-                    record[2] = 0.0f + gain.z;
-                    record[3] = 0.0;
+                    // written once, read once by the other kernel: kept from displacing the scene in the caches
+                    Double2* out = reinterpret_cast<Double2*>(record);
+                    __builtin_nontemporal_store(Double2{0.0f + gain.x, 0.0f + gain.y}, out);
+                    __builtin_nontemporal_store(Double2{0.0f + gain.z, 0.0}, out + 1);
                     st = ST_NEED;
                 } else {
                     st = ST_NEWRAY;
