@@ -2,6 +2,8 @@
 bit for bit: no primitive at all, one and two triangles (a 4-wide node with empty slots), degenerate
 triangles, coordinates outside the single-precision range, hollow spheres, spheres only.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -81,6 +83,33 @@ def test_coordinates_outside_the_single_precision_range(api, orc):
     rng = np.random.default_rng(8)
     triangles = rng.uniform(-3, 3, (200, 9)) * 1.0e6 + np.tile([4.0e7, -2.0e7, 1.0e7], 3)
     tri, _ = _compare(api, orc, _scene(api, triangles), (4.0e7, -2.0e7, 4.0e7), (4.0e7, -2.0e7, 1.0e7), aperture=1.0e3)
+    assert (tri >= 0).any()
+
+
+def test_coordinates_near_the_edge_of_the_single_precision_range(api, orc):
+    """Small triangles far from the origin, still inside the range of the single-precision nodes: a float
+    is 0.06 wide out there, so the planes, the ray origin and their difference are all badly rounded.
+    The conservative test must still never skip a box the exact test accepts (counted by the
+    cross-checking build), and the bytes must match."""
+    from oracle.bindings import make_desc
+    rng = np.random.default_rng(12)
+    centre = np.array([9.0e5, -9.0e5, 9.0e5])
+    triangles = rng.uniform(-6, 6, (300, 1, 3)) + rng.uniform(-1.5, 1.5, (300, 3, 3)) + centre
+    arrays = _scene(api, triangles.reshape(-1, 9))
+    desc, keep = make_desc(arrays)
+    os.environ["PT_STATS"] = "1"
+    try:
+        device = api.DeviceScene(desc, keepalive=keep)
+        cam = api.camera_look_at(centre + [0.0, 3.0, 30.0], centre, 0.7, 0.05)
+        frame = api.camera_frame(cam, 4 / 3, 48, 36, sample_count=4, max_bounces=12)
+        got = device.render(frame)
+        stats = device.last_render_stats()
+    finally:
+        del os.environ["PT_STATS"]
+    assert stats["node_lanes"] > 0 and stats["unsafe_skips"] == 0
+    checker = orc.scene_create(arrays)
+    assert same_bits(got, checker.render(frame, threads=4))
+    tri, _ = device.primary_hits(frame)
     assert (tri >= 0).any()
 
 
