@@ -565,11 +565,9 @@ struct Tunables {
     int leaf_threshold = 24;
     int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
     int distrust_mask = -1;             // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winner to the fallback)
-    bool xcd_bands = false;             // PT_XCD=1: one chunk counter per XCD (tile rows dealt to the XCDs) instead of one for the chip
     Tunables() {
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
         if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
-        if (const char* v = std::getenv("PT_XCD")) xcd_bands = std::atoi(v) != 0;
         if (const char* v = std::getenv("PT_STACK_SLOTS")) stack_slots = std::atoi(v);
         if (const char* v = std::getenv("PT_DISTRUST_MASK")) distrust_mask = std::atoi(v);
         if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
@@ -657,7 +655,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     }
     unsigned int* counter = static_cast<unsigned int*>(scene->counters.p);
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(scene->counters.p) + 512);
-    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 1024, stream));   // chunk counters (one per 64-byte line) + profiling counters
+    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 1024, stream));   // the unit counter + profiling counters
 
     FrameParams fp = frame_params(*frame);
     const int sample_end = frame->sample_begin + frame->sample_count;
@@ -668,18 +666,17 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         WorkParams wp;
         wp.tiles_x = static_cast<int>(tiles_x);
         wp.groups_per_tile = (fp.sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
-        wp.chunk_count = real_tiles * wp.groups_per_tile;
-        wp.tile_rows = static_cast<int>(real_tiles / tiles_x);
-        wp.bands = t.xcd_bands ? 8 : 1;
+        const long long units = real_tiles * wp.groups_per_tile * SAMPLES_PER_CHUNK;     // 64 paths each
+        if (units >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld units of 64 paths", units);
+        wp.unit_count = static_cast<unsigned int>(units);
         wp.shade_threshold = t.shade_threshold;
         wp.leaf_threshold = t.leaf_threshold;
         wp.stack_slots = stack_slots;
         wp.distrust_mask = t.distrust_mask;
-        if (wp.chunk_count >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld chunks", wp.chunk_count);
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
         first = false;
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
-                                                                          (wp.chunk_count + 3) / 4));
+                                                                          (units + 3) / 4));
         const int rc = trace_paths(t.stats, node32, blocks, stack_bytes, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats, nullptr);
         if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,

@@ -37,9 +37,7 @@ constexpr int MAX_WF_STACK_SLOTS = 36; // per-lane stack slots a block is given 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
     int groups_per_tile;         // ceil(sample_count / SAMPLES_PER_CHUNK)
-    long long chunk_count;       // tiles_x * tile_rows * groups_per_tile
-    int tile_rows;               // rows of tiles rendered by this launch (this GPU's shard)
-    int bands;                   // 8: one chunk counter per XCD, tile row r belongs to band r % 8; 1: a single counter
+    unsigned int unit_count;     // tiles of this launch (this GPU's shard) * groups_per_tile * SAMPLES_PER_CHUNK: 64 paths each
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
@@ -59,7 +57,7 @@ struct TraceArgs {
     FrameParams f;
     WorkParams w;
     double* rgb;
-    unsigned int* next_chunk;
+    unsigned int* next_unit;
     unsigned long long* stats;
 };
 // The argument struct behind a pointer the compiler must treat as new at this point: what is read through
@@ -110,14 +108,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     const TriLeaf tri_leaf{s.tris};
     const SphLeaf sph_leaf{s.spheres};
 
-    // wave-uniform work state: the chunk being handed out and where its tile and samples lie
-    unsigned int chunk = 0;
-    int chunk_next = 0, chunk_size = 0, chunk_row0 = 0, chunk_col0 = 0, chunk_sample0 = 0;
-    bool work_left = true;          // chunks may remain on the counter
-    int pool_first = 0, pool_taken = 64;   // the pool holds paths pool_first .. +63 of the chunk; entries below pool_taken are gone
-    int bands_tried = 0;
-    // HW_REG_XCC_ID (hardware register 20, bits 3:0): which of the 8 XCDs this wave runs on
-    const int home_band = (w.bands > 1) ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % w.bands : 0;
+    // wave-uniform work state: the units of 64 paths drawn and where the current one's tile lies
+    unsigned int unit_next = 0, unit_end = 0;   // the units drawn and not yet started
+    int unit_row0 = 0, unit_col0 = 0, unit_group = 0;
+    bool work_left = true;          // units may remain on the counter
+    long long pool_first = 0;       // colour-scratch slot of the pool's first path
+    int pool_taken = 64;            // entries of the pool below this are gone
     WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = (STATS == 2) ? clock64() : 0;
     long long t0 = 0;
@@ -125,7 +121,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     // per-lane path state
     int st = ST_NEED;
     int cur = 0, sp = 0, bounce = 0, best_i = -1;
-    long long slot = 0;                 // chunk * CHUNK_PATHS + j of the lane's path
+    long long slot = 0;                 // place of the lane's path in the colour scratch: unit * 64 + pixel of the tile
     bool tie = false, tie_s = false;    // a second triangle / sphere at exactly the best triangle / sphere distance
     double best_t = REAL_MAX, cut = REAL_MAX;
     float cut32 = 0.0f;
@@ -257,9 +253,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                 ++bounce;
                 if (!go_on || bounce >= f.max_bounces) {
                     // every earlier vertex added +-0 (see the file header): colour = 0 + last term
-                    const long long c = slot / CHUNK_PATHS;
-                    const int j = (int)(slot % CHUNK_PATHS);
-                    double* record = fetched->rgb + rgb_index(c, 0, j);
+                    double* record = fetched->rgb + 4 * slot;
                     // written once, read once by the other kernel: kept from displacing the scene in the caches
                     Double2* out = reinterpret_cast<Double2*>(record);
                     __builtin_nontemporal_store(Double2{0.0f + gain.x, 0.0f + gain.y}, out);
@@ -273,59 +267,55 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             // ---------------- hand new paths to idle lanes
             // Camera rays are made 64 at a time by the whole wave (all lanes busy, whatever their own path is
             // doing) and parked in LDS; an idle lane then only picks one up.
-            const WorkParams& cold = *(const WorkParams*)&fetched->w;       // how chunks are dealt: read when a chunk is drawn
+            const WorkParams& cold = *(const WorkParams*)&fetched->w;       // how work is dealt: read when a unit is drawn
             for (;;) {
                 const unsigned long long m_need = __ballot(st == ST_NEED);
                 if (m_need == 0ull) break;
                 if (pool_taken == 64) {
-                    if (!work_left) break;
-                    if (chunk_next >= chunk_size) {
-                        // Chunks are dealt per band: tile row r belongs to band r % bands and each band has its own
-                        // counter.  A wave draws from the band of its XCD first, so the waves sharing an L2 work on
-                        // the same rows of tiles; when that band is empty it helps the next one.
-                        const unsigned int per_row = (unsigned int)cold.tiles_x * (unsigned int)cold.groups_per_tile;
-                        int band = -1;
-                        unsigned int c = 0;
-                        while (bands_tried < cold.bands) {
-                            const int b = (home_band + bands_tried) % cold.bands;
-                            const unsigned int rows_in_band = (unsigned int)((cold.tile_rows - b + cold.bands - 1) / cold.bands);
-                            unsigned int v = 0;
-                            if (lane == 0) v = atomicAdd(fetched->next_chunk + 16 * b, 1u);
-                            v = __builtin_amdgcn_readfirstlane(v);
-                            if (v < rows_in_band * per_row) { band = b; c = v; break; }
-                            ++bands_tried;                       // that band is finished for good
-                        }
-                        if (band < 0) { work_left = false; break; }
-                        const unsigned int band_row = c / per_row;
-                        const unsigned int rest = c - band_row * per_row;
-                        const unsigned int tile_col = rest / (unsigned int)cold.groups_per_tile;
-                        const int group = (int)(rest - tile_col * (unsigned int)cold.groups_per_tile);
-                        const unsigned int tile_row = band_row * (unsigned int)cold.bands + (unsigned int)band;
-                        chunk = (tile_row * (unsigned int)cold.tiles_x + tile_col) * (unsigned int)cold.groups_per_tile + (unsigned int)group;
-                        chunk_next = 0;
-                        chunk_col0 = (int)tile_col * 8;
-                        chunk_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
-                        chunk_sample0 = f.sample_begin + group * SAMPLES_PER_CHUNK;
-                        chunk_size = 64 * min(SAMPLES_PER_CHUNK, f.sample_count - group * SAMPLES_PER_CHUNK);
+                    // Work is dealt in units of 64 paths: unit u is sample (u % 16) of sample group g of tile t, in
+                    // the order of the colour scratch (u = (t * groups + g) * 16 + sample).  A wave draws 16 units
+                    // (one tile's sample group) at a time.  Drawing single units towards the end of a launch was
+                    // measured and changes nothing: a launch ends with the few paths that bounce longest.
+                    if (unit_next == unit_end) {
+                        if (!work_left) break;
+                        unsigned int first = 0;
+                        if (lane == 0) first = atomicAdd(fetched->next_unit, (unsigned int)SAMPLES_PER_CHUNK);
+                        first = __builtin_amdgcn_readfirstlane(first);
+                        if (first >= cold.unit_count) { work_left = false; break; }
+                        unit_next = first;
+                        unit_end = min(first + (unsigned int)SAMPLES_PER_CHUNK, cold.unit_count);
                     }
-                    // the next sample of the chunk's 64 pixels: lane l makes the ray of pixel l (pixels of a
-                    // partial tile that lie outside the image get a ray too; nobody will pick it up)
-                    const int row = min(chunk_row0 + (lane >> 3), f.height - 1);
-                    const int column = min(chunk_col0 + (lane & 7), f.width - 1);
-                    const Ray made = camera_ray(f, row, column, chunk_sample0 + (chunk_next >> 6));
+                    const unsigned int unit = unit_next++;
+                    const unsigned int in_group = unit % SAMPLES_PER_CHUNK;
+                    if (in_group == 0) {
+                        const unsigned int chunk = unit / SAMPLES_PER_CHUNK;
+                        const unsigned int per_row = (unsigned int)cold.tiles_x * (unsigned int)cold.groups_per_tile;
+                        const unsigned int tile_row = chunk / per_row;
+                        const unsigned int rest = chunk - tile_row * per_row;
+                        const unsigned int tile_col = rest / (unsigned int)cold.groups_per_tile;
+                        unit_group = (int)(rest - tile_col * (unsigned int)cold.groups_per_tile);
+                        unit_col0 = (int)tile_col * 8;
+                        unit_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
+                    }
+                    const int sample = unit_group * SAMPLES_PER_CHUNK + (int)in_group;
+                    if (sample >= f.sample_count) continue;          // the last group of a sample range may be partial
+                    // lane l makes the ray of the tile's pixel l (pixels of a partial tile that lie outside the
+                    // image get a ray too; nobody will pick it up)
+                    const int row = min(unit_row0 + (lane >> 3), f.height - 1);
+                    const int column = min(unit_col0 + (lane & 7), f.width - 1);
+                    const Ray made = camera_ray(f, row, column, f.sample_begin + sample);
                     pool[0][lane] = made.o.x; pool[1][lane] = made.o.y; pool[2][lane] = made.o.z;
                     pool[3][lane] = made.d.x; pool[4][lane] = made.d.y; pool[5][lane] = made.d.z;
-                    pool_first = chunk_next;
+                    pool_first = (long long)unit * 64;
                     pool_taken = 0;
-                    chunk_next += 64;
                 }
                 const int rank = __popcll(m_need & ((1ull << lane) - 1ull));
                 const int entry = pool_taken + rank;
                 if (st == ST_NEED && entry < 64) {
-                    const int row = chunk_row0 + (entry >> 3);
-                    const int column = chunk_col0 + (entry & 7);
+                    const int row = unit_row0 + (entry >> 3);
+                    const int column = unit_col0 + (entry & 7);
                     if (row < f.row_end && column < f.width) {
-                        slot = (long long)chunk * CHUNK_PATHS + pool_first + entry;
+                        slot = pool_first + entry;
                         ray = Ray{D3{pool[0][entry], pool[1][entry], pool[2][entry]}, D3{pool[3][entry], pool[4][entry], pool[5][entry]}};
                         att = D3{1.0f, 1.0f, 1.0f};
                         bounce = 0;
