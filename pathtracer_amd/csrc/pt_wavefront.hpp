@@ -37,7 +37,8 @@ constexpr int MAX_WF_STACK_SLOTS = 36; // per-lane stack slots a block is given 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
     int groups_per_tile;         // ceil(sample_count / SAMPLES_PER_CHUNK)
-    unsigned int unit_count;     // tiles of this launch (this GPU's shard) * groups_per_tile * SAMPLES_PER_CHUNK: 64 paths each
+    unsigned int tile_count;     // tiles of this launch (this GPU's shard)
+    unsigned int unit_count;     // ceil(tile_count / 16) * groups_per_tile * 256: units of 64 paths on the counter
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     const SphLeaf sph_leaf{s.spheres};
 
     // wave-uniform work state: the units of 64 paths drawn and where the current one's tile lies
-    unsigned int unit_next = 0, unit_end = 0;   // the units drawn and not yet started
-    int unit_row0 = 0, unit_col0 = 0, unit_group = 0;
+    unsigned int unit_next = 0, unit_end = 0, draw_tile0 = 0;   // the units drawn and not yet started; the draw's first tile
+    int unit_row0 = 0, unit_col0 = 0, draw_group = 0, draw_shift = 0;
     bool work_left = true;          // units may remain on the counter
     long long pool_first = 0;       // colour-scratch slot of the pool's first path
     int pool_taken = 64;            // entries of the pool below this are gone
@@ -272,10 +273,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                 const unsigned long long m_need = __ballot(st == ST_NEED);
                 if (m_need == 0ull) break;
                 if (pool_taken == 64) {
-                    // Work is dealt in units of 64 paths: unit u is sample (u % 16) of sample group g of tile t, in
-                    // the order of the colour scratch (u = (t * groups + g) * 16 + sample).  A wave draws 16 units
-                    // (one tile's sample group) at a time.  Drawing single units towards the end of a launch was
-                    // measured and changes nothing: a launch ends with the few paths that bounce longest.
+                    // Work is dealt in units of 64 paths (one sample of one 8x8 tile), 16 units per draw from the
+                    // counter.  Tiles differ a lot in cost (a pixel whose paths get inside a closed mesh bounces to
+                    // the limit every time), so the 16 units of a draw are 16 DIFFERENT tiles, one sample each:
+                    // 16 neighbouring tiles x the 16 samples of a group form a square of 256 units, and draw d of
+                    // the square takes sample (k + d) % 16 of its tile k.  A costly tile then weighs on 16 draws
+                    // by a sixteenth each instead of on one draw entirely.
                     if (unit_next == unit_end) {
                         if (!work_left) break;
                         unsigned int first = 0;
@@ -283,22 +286,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         first = __builtin_amdgcn_readfirstlane(first);
                         if (first >= cold.unit_count) { work_left = false; break; }
                         unit_next = first;
-                        unit_end = min(first + (unsigned int)SAMPLES_PER_CHUNK, cold.unit_count);
+                        unit_end = first + (unsigned int)SAMPLES_PER_CHUNK;
+                        const unsigned int draw = first / SAMPLES_PER_CHUNK;
+                        const unsigned int square = draw / SAMPLES_PER_CHUNK;
+                        draw_shift = (int)(draw % SAMPLES_PER_CHUNK);
+                        const unsigned int tile_block = square / (unsigned int)cold.groups_per_tile;
+                        draw_group = (int)(square - tile_block * (unsigned int)cold.groups_per_tile);
+                        draw_tile0 = tile_block * SAMPLES_PER_CHUNK;
                     }
-                    const unsigned int unit = unit_next++;
-                    const unsigned int in_group = unit % SAMPLES_PER_CHUNK;
-                    if (in_group == 0) {
-                        const unsigned int chunk = unit / SAMPLES_PER_CHUNK;
-                        const unsigned int per_row = (unsigned int)cold.tiles_x * (unsigned int)cold.groups_per_tile;
-                        const unsigned int tile_row = chunk / per_row;
-                        const unsigned int rest = chunk - tile_row * per_row;
-                        const unsigned int tile_col = rest / (unsigned int)cold.groups_per_tile;
-                        unit_group = (int)(rest - tile_col * (unsigned int)cold.groups_per_tile);
-                        unit_col0 = (int)tile_col * 8;
-                        unit_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
-                    }
-                    const int sample = unit_group * SAMPLES_PER_CHUNK + (int)in_group;
-                    if (sample >= f.sample_count) continue;          // the last group of a sample range may be partial
+                    const unsigned int k = unit_next % SAMPLES_PER_CHUNK;
+                    ++unit_next;
+                    const unsigned int tile = draw_tile0 + k;
+                    const int in_group = (int)((k + (unsigned int)draw_shift) % SAMPLES_PER_CHUNK);
+                    const int sample = draw_group * SAMPLES_PER_CHUNK + in_group;
+                    // the last square of a launch and the last group of a sample range may be partial
+                    if (tile >= cold.tile_count || sample >= f.sample_count) continue;
+                    const unsigned int tile_row = tile / (unsigned int)cold.tiles_x;
+                    const unsigned int tile_col = tile - tile_row * (unsigned int)cold.tiles_x;
+                    unit_col0 = (int)tile_col * 8;
+                    unit_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
+                    const unsigned int unit_in_scratch = (tile * (unsigned int)cold.groups_per_tile + (unsigned int)draw_group) * SAMPLES_PER_CHUNK + (unsigned int)in_group;
                     // lane l makes the ray of the tile's pixel l (pixels of a partial tile that lie outside the
                     // image get a ray too; nobody will pick it up)
                     const int row = min(unit_row0 + (lane >> 3), f.height - 1);
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     const Ray made = camera_ray(f, row, column, f.sample_begin + sample);
                     pool[0][lane] = made.o.x; pool[1][lane] = made.o.y; pool[2][lane] = made.o.z;
                     pool[3][lane] = made.d.x; pool[4][lane] = made.d.y; pool[5][lane] = made.d.z;
-                    pool_first = (long long)unit * 64;
+                    pool_first = (long long)unit_in_scratch * 64;
                     pool_taken = 0;
                 }
                 const int rank = __popcll(m_need & ((1ull << lane) - 1ull));
