@@ -666,7 +666,8 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         WorkParams wp;
         wp.tiles_x = static_cast<int>(tiles_x);
         wp.groups_per_tile = (fp.sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
-        const long long units = ((real_tiles + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK) * wp.groups_per_tile * SAMPLES_PER_CHUNK * SAMPLES_PER_CHUNK;   // 64 paths each
+        const long long tile_rows = real_tiles / tiles_x;
+        const long long units = ((tiles_x + 3) / 4) * ((tile_rows + 3) / 4) * wp.groups_per_tile * SAMPLES_PER_CHUNK * SAMPLES_PER_CHUNK;   // 64 paths each
         wp.tile_count = static_cast<unsigned int>(real_tiles);
         if (units >= (1ll << 31)) return pt::fail(PT_ERR_UNSUPPORTED, "frame too large for one batch: %lld units of 64 paths", units);
         wp.unit_count = static_cast<unsigned int>(units);

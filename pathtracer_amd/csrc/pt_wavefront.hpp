@@ -38,7 +38,7 @@ struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
     int groups_per_tile;         // ceil(sample_count / SAMPLES_PER_CHUNK)
     unsigned int tile_count;     // tiles of this launch (this GPU's shard)
-    unsigned int unit_count;     // ceil(tile_count / 16) * groups_per_tile * 256: units of 64 paths on the counter
+    unsigned int unit_count;     // blocks of 4x4 tiles * groups_per_tile * 256: units of 64 paths on the counter
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     const SphLeaf sph_leaf{s.spheres};
 
     // wave-uniform work state: the units of 64 paths drawn and where the current one's tile lies
-    unsigned int unit_next = 0, unit_end = 0, draw_tile0 = 0;   // the units drawn and not yet started; the draw's first tile
+    unsigned int unit_next = 0, unit_end = 0, draw_tile_row0 = 0, draw_tile_col0 = 0;   // the units drawn and not yet started; the draw's first tile
     int unit_row0 = 0, unit_col0 = 0, draw_group = 0, draw_shift = 0;
     bool work_left = true;          // units may remain on the counter
     long long pool_first = 0;       // colour-scratch slot of the pool's first path
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // Work is dealt in units of 64 paths (one sample of one 8x8 tile), 16 units per draw from the
                     // counter.  Tiles differ a lot in cost (a pixel whose paths get inside a closed mesh bounces to
                     // the limit every time), so the 16 units of a draw are 16 DIFFERENT tiles, one sample each:
-                    // 16 neighbouring tiles x the 16 samples of a group form a square of 256 units, and draw d of
-                    // the square takes sample (k + d) % 16 of its tile k.  A costly tile then weighs on 16 draws
+                    // a block of 4x4 neighbouring tiles x the 16 samples of a group form a square of 256 units, and
+                    // draw d of the square takes sample (k + d) % 16 of its tile k.  A costly tile then weighs on 16 draws
                     // by a sixteenth each instead of on one draw entirely.
                     if (unit_next == unit_end) {
                         if (!work_left) break;
@@ -292,17 +292,19 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         draw_shift = (int)(draw % SAMPLES_PER_CHUNK);
                         const unsigned int tile_block = square / (unsigned int)cold.groups_per_tile;
                         draw_group = (int)(square - tile_block * (unsigned int)cold.groups_per_tile);
-                        draw_tile0 = tile_block * SAMPLES_PER_CHUNK;
+                        const unsigned int blocks_x = ((unsigned int)cold.tiles_x + 3u) / 4u;
+                        const unsigned int block_row = tile_block / blocks_x;
+                        draw_tile_row0 = block_row * 4u;
+                        draw_tile_col0 = (tile_block - block_row * blocks_x) * 4u;
                     }
                     const unsigned int k = unit_next % SAMPLES_PER_CHUNK;
                     ++unit_next;
-                    const unsigned int tile = draw_tile0 + k;
+                    const unsigned int tile_row = draw_tile_row0 + (k >> 2), tile_col = draw_tile_col0 + (k & 3u);
+                    const unsigned int tile = tile_row * (unsigned int)cold.tiles_x + tile_col;
                     const int in_group = (int)((k + (unsigned int)draw_shift) % SAMPLES_PER_CHUNK);
                     const int sample = draw_group * SAMPLES_PER_CHUNK + in_group;
-                    // the last square of a launch and the last group of a sample range may be partial
-                    if (tile >= cold.tile_count || sample >= f.sample_count) continue;
-                    const unsigned int tile_row = tile / (unsigned int)cold.tiles_x;
-                    const unsigned int tile_col = tile - tile_row * (unsigned int)cold.tiles_x;
+                    // the squares at the right and upper edge and the last group of a sample range may be partial
+                    if (tile_col >= (unsigned int)cold.tiles_x || tile >= cold.tile_count || sample >= f.sample_count) continue;
                     unit_col0 = (int)tile_col * 8;
                     unit_row0 = f.row_begin + ((int)tile_row * f.shard_count + f.shard_index) * 8;
                     const unsigned int unit_in_scratch = (tile * (unsigned int)cold.groups_per_tile + (unsigned int)draw_group) * SAMPLES_PER_CHUNK + (unsigned int)in_group;
