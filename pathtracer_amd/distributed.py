@@ -8,6 +8,8 @@ byte-identical to a single-GPU render.  The only exchange is the final gather of
 rows to rank 0 (RCCL over xGMI on GPUs, gloo on CPU): 32 B per pixel, once per frame, or 4 B per
 pixel when only the tone-mapped image is wanted (`gather_image8`).
 """
+import functools
+
 import torch
 import torch.distributed as dist
 
@@ -21,6 +23,12 @@ def shard_rows(height, rank, world, row_begin=0):
     return rows[block % world == rank]
 
 
+@functools.lru_cache(maxsize=64)
+def _rows_on_device(height, rank, world, device):
+    """shard_rows(...) as an index tensor on `device`, made once: a frame loop calls the gather every frame."""
+    return shard_rows(height, rank, world).to(device)
+
+
 def gather_rows(accum, height, width, rank, world, dst=0, group=None):
     """accum: (height, width, 4) tensor (float64 sums, or uint8 image) holding this rank's rows
     (others are ignored).  After the call rank `dst` holds every rank's rows in place; other ranks
@@ -28,19 +36,20 @@ def gather_rows(accum, height, width, rank, world, dst=0, group=None):
     if world == 1:
         return accum
     assert accum.shape == (height, width, 4)
-    counts = [len(shard_rows(height, r, world)) for r in range(world)]
+    rows_of = [_rows_on_device(height, r, world, accum.device) for r in range(world)]
+    counts = [len(rows) for rows in rows_of]
     longest = max(counts)
-    mine = shard_rows(height, rank, world).to(accum.device)
-    send = torch.zeros((longest, width, 4), dtype=accum.dtype, device=accum.device)
+    mine = rows_of[rank]
+    send = torch.empty((longest, width, 4), dtype=accum.dtype, device=accum.device)
     send[: len(mine)] = accum.index_select(0, mine)
+    send[len(mine):] = 0
     if rank == dst:
         received = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, received, dst=dst, group=group)
         for r in range(world):
             if r == dst:
                 continue
-            rows = shard_rows(height, r, world).to(accum.device)
-            accum.index_copy_(0, rows, received[r][: counts[r]])
+            accum.index_copy_(0, rows_of[r], received[r][: counts[r]])
     else:
         dist.gather(send, None, dst=dst, group=group)
     return accum
