@@ -7,9 +7,9 @@
 // wave idles.  A path's colour, however, is a pure function of (row, column, sample): it can
 // be computed by any lane at any time.  So:
 //
-//   trace_paths_kernel   persistent waves pull chunks of 1024 paths (one 8x8 tile x 16
-//                        samples) from a counter in HBM and write each path's colour to
-//                        `rgb`; a lane that finishes a path takes the next one, so all 64
+//   trace_paths_kernel   persistent waves draw 1024 paths at a time (one sample each of 16
+//                        neighbouring 8x8 tiles) from a counter in HBM and write each path's colour
+//                        to `rgb`; a lane that finishes a path takes the next one, so all 64
 //                        lanes stay busy until the frame runs out of work.  Inside the wave,
 //                        lanes are regrouped with ballots: node steps, leaf tests and
 //                        shading each run when enough lanes want them, never one lane at a time.
@@ -47,8 +47,9 @@ struct WorkParams {
 };
 
 // rgb layout: [chunk][CHUNK_PATHS][r, g, b, 0] doubles, one 32-byte record per path, written whole
-// (two 16-byte stores that fill one 32-byte sector); path j of a chunk is sample (j / 64) of the
-// chunk's sample group at pixel (j % 64) of the chunk's tile.
+// (two 16-byte stores that fill one 32-byte sector); chunk = tile * groups + sample group, and path j
+// of a chunk is sample (j / 64) of that group at pixel (j % 64) of the tile.  (The order in which the
+// paths are handed out is another matter: see the refill of the kernel.)
 PT_DEV long long rgb_index(long long chunk, int channel, int j) { return (chunk * CHUNK_PATHS + j) * 4 + channel; }
 
 // Everything the kernel is given, as one argument: the kernel-argument segment then holds exactly this
