@@ -255,6 +255,14 @@ def test_full_size_properties(scenes, api):
         assert same_bits(image[row], expect.reshape(h, w, 4)[row])
 
 
+def test_full_frame_matches_checker(scenes):
+    """The whole 1920x1080 frame of the benchmark scene, 16 samples per pixel (33 M paths: one whole sample group, the kernel's
+    steady state with every wave busy), against the CPU checker: every double."""
+    host, device, checker = scenes("chess32")
+    frame = host.frame(1920, 1080, sample_count=16, max_bounces=50)
+    assert same_bits(device.render(frame), checker.render(frame, threads=16))
+
+
 def test_live_reference_build(scenes, ref, api):
     """Where the reference's own build is present: its render of its own scene, bit for bit."""
     host, device, _ = scenes("rook")
