@@ -263,6 +263,17 @@ def test_full_frame_matches_checker(scenes):
     assert same_bits(device.render(frame), checker.render(frame, threads=16))
 
 
+@pytest.mark.parametrize("name, size, spp, bounces", [
+    ("spheres", (1200, 800), 4, 50),      # the reference's own scene at its own size: spheres and no triangle
+    ("cornell", (512, 512), 4, 50),       # long paths, shared diagonals (ties)
+    ("mixed", (960, 540), 4, 16),         # every material
+])
+def test_large_frames_of_the_other_scenes_match_checker(scenes, name, size, spp, bounces):
+    host, device, checker = scenes(name)
+    frame = host.frame(*size, sample_count=spp, max_bounces=bounces)
+    assert same_bits(device.render(frame), checker.render(frame, threads=16))
+
+
 def test_live_reference_build(scenes, ref, api):
     """Where the reference's own build is present: its render of its own scene, bit for bit."""
     host, device, _ = scenes("rook")
