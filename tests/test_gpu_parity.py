@@ -29,8 +29,8 @@ def scenes(api, orc):
                 host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, name + ".triangles"))
             elif name in ("spheres", "cornell"):
                 host = api.HostScene({"spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}[name])
-            elif name == "grid2":
-                host = api.HostScene(abi.PT_SCENE_CHESS_GRID, MODELS, 2)
+            elif name.startswith("grid"):
+                host = api.HostScene(abi.PT_SCENE_CHESS_GRID, MODELS, int(name[4:]))
             else:
                 kind = {"chess6": abi.PT_SCENE_CHESS6_ROW, "chess32": abi.PT_SCENE_CHESS32, "mixed": abi.PT_SCENE_CHESS32_MIXED}[name]
                 host = api.HostScene(kind, MODELS)
@@ -271,6 +271,18 @@ def test_full_frame_matches_checker(scenes):
 def test_large_frames_of_the_other_scenes_match_checker(scenes, name, size, spp, bounces):
     host, device, checker = scenes(name)
     frame = host.frame(*size, sample_count=spp, max_bounces=bounces)
+    assert same_bits(device.render(frame), checker.render(frame, threads=16))
+
+
+def test_ten_million_triangles_match_checker(scenes):
+    """25 boards, 10.56 M triangles: 1.35 GB of triangle records and 5 M four-wide nodes, so byte offsets
+    pass 2^31 and the scene no longer fits any cache."""
+    host, device, checker = scenes("grid5")
+    assert host.desc.triangle_count == 10564950
+    frame = host.frame(160, 90, sample_count=2, max_bounces=50)
+    tri, sph = device.primary_hits(frame)
+    tri_c, sph_c = checker.primary_hits(frame)
+    assert np.array_equal(tri, tri_c) and np.array_equal(sph, sph_c) and tri.max() > 2 ** 23
     assert same_bits(device.render(frame), checker.render(frame, threads=16))
 
 
