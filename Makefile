@@ -17,7 +17,9 @@ HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp $(CS
 HOST_OBJS := $(HOST_SRCS:.cpp=.o)
 HIP_OBJS  := $(CSRC)/pt_gpu.o
 
-all: $(LIB) oracle
+CONSUMER := tests/consumer/render_rook
+
+all: $(LIB) oracle $(CONSUMER)
 
 $(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/pt_internal.h $(CSRC)/pt_traverse_host.h include/pathtracer_amd.h
 	$(CXX) $(HOSTFLAGS) -c -o $@ $<
@@ -28,11 +30,15 @@ $(CSRC)/pt_gpu.o: $(CSRC)/pt_gpu.hip $(CSRC)/pt_device.hpp $(CSRC)/pt_traverse.h
 $(LIB): $(HOST_OBJS) $(HIP_OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(HOST_OBJS) $(HIP_OBJS) -pthread
 
+# A plain C caller of the public header (what a maintainer of the reference would write), run by the GPU tests.
+$(CONSUMER): tests/consumer/render_rook.c include/pathtracer_amd.h $(LIB)
+	gcc -std=c11 -O2 -ffp-contract=off -Wall -Wextra -Iinclude -o $@ $< -Lpathtracer_amd -lpathtracer_amd -Wl,-rpath,'$$ORIGIN/../../pathtracer_amd'
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(HOST_OBJS) $(HIP_OBJS) $(LIB)
+	rm -f $(HOST_OBJS) $(HIP_OBJS) $(LIB) $(CONSUMER)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

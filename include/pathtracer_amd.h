@@ -202,7 +202,10 @@ void pt_scene_destroy(PtScene* scene);
 int pt_render(PtScene* scene, const PtFrame* frame, double* accum);
 /* Same, with `accum_device` in the HBM of the scene's device and the work
  * enqueued on `hip_stream` (a hipStream_t; null = the default stream).  Returns
- * after the launch; the caller synchronises the stream. */
+ * after the launch; the caller synchronises the stream.  A scene handle owns one work counter and
+ * one colour workspace: launches through one handle must be ordered (one stream, or waited for).
+ * A launch on a different stream while the handle's previous launch is still running returns
+ * PT_ERR_UNSUPPORTED and renders nothing; overlapping frames need one handle each. */
 int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
 
 /* The tone-map of src/main.cpp:1024-1034 on the GPU: `accum_device` (4*pixel_count

@@ -292,6 +292,7 @@ struct PtScene {
     // wavefront kernel: per-path colours, the chunk counter and the profiling counters
     DeviceBuffer rgb, counters;
     size_t rgb_bytes = 0;
+    void* last_counters = nullptr;      // counters of the most recent wavefront launch (the scene's own or the static workspace's)
     bool albedo_bounded = false;        // every albedo finite with |albedo| <= 1
     int compute_units = 0, blocks_per_cu = 0, occupancy_variant = -1;
     unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -586,15 +587,25 @@ int launch_pixels_kernel(PtScene* scene, const PtFrame* frame, double* accum_dev
     return PT_OK;
 }
 
+// Device memory a wavefront launch writes besides the accumulation buffer.
+struct TraceOutputs {
+    double* rgb = nullptr;
+    unsigned int* counter = nullptr;
+    unsigned long long* stats = nullptr;
+    int* hit_triangle = nullptr;     // both null unless the launch reports first-vertex indices
+    int* hit_sphere = nullptr;
+};
+
 template <int STATS, bool NODE32, bool MERGED>
 int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
-                       const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
+                       const WorkParams& wp, const TraceOutputs& out, int* blocks_per_cu) {
     auto kernel = trace_paths_kernel<STATS, NODE32, MERGED>;
     if (blocks_per_cu != nullptr) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, BLOCK_THREADS, stack_bytes));
         return PT_OK;
     }
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream, TraceArgs{dev, fp, wp, rgb, counter, stats});
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream,
+                       TraceArgs{dev, fp, wp, out.rgb, out.counter, out.stats, out.hit_triangle, out.hit_sphere});
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -602,38 +613,76 @@ int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, 
 // Dispatch over the compile-time switches; with `blocks_per_cu` set it only queries occupancy.
 template <int STATS>
 int trace_paths_variant(bool node32, bool merged, unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev,
-                        const FrameParams& fp, const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats,
-                        int* blocks_per_cu) {
-    if (!node32) return launch_trace_paths<STATS, false, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
-    if (merged) return launch_trace_paths<STATS, true, true>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
-    return launch_trace_paths<STATS, true, false>(blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+                        const FrameParams& fp, const WorkParams& wp, const TraceOutputs& out, int* blocks_per_cu) {
+    if (!node32) return launch_trace_paths<STATS, false, false>(blocks, stack_bytes, stream, dev, fp, wp, out, blocks_per_cu);
+    if (merged) return launch_trace_paths<STATS, true, true>(blocks, stack_bytes, stream, dev, fp, wp, out, blocks_per_cu);
+    return launch_trace_paths<STATS, true, false>(blocks, stack_bytes, stream, dev, fp, wp, out, blocks_per_cu);
 }
 
 int trace_paths(int stats_build, bool node32, unsigned blocks, size_t stack_bytes, hipStream_t stream, const DeviceScene& dev, const FrameParams& fp,
-                const WorkParams& wp, double* rgb, unsigned int* counter, unsigned long long* stats, int* blocks_per_cu) {
+                const WorkParams& wp, const TraceOutputs& out, int* blocks_per_cu) {
     const bool merged = node32 && dev.sphere_base != 0x7fffffff;
-    if (stats_build == 1) return trace_paths_variant<1>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
-    if (stats_build == 2) return trace_paths_variant<2>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
-    return trace_paths_variant<0>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, rgb, counter, stats, blocks_per_cu);
+    if (stats_build == 1) return trace_paths_variant<1>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, out, blocks_per_cu);
+    if (stats_build == 2) return trace_paths_variant<2>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, out, blocks_per_cu);
+    return trace_paths_variant<0>(node32, merged, blocks, stack_bytes, stream, dev, fp, wp, out, blocks_per_cu);
+}
+
+// Where a launch keeps its per-path colours and its counters: the scene's own buffers, allocated and grown
+// on demand (`fixed` false), or memory the caller of launch_wavefront provides and nothing may be allocated.
+struct Workspace {
+    double* rgb = nullptr;
+    size_t rgb_bytes = 0;
+    void* counters = nullptr;      // 1024 bytes: unit counter, then (at +512) the profiling counters
+    bool fixed = false;
+    int* hit_triangle = nullptr;   // set by pt_primary_hits: the launch reports the first-vertex indices of both traversals
+    int* hit_sphere = nullptr;
+};
+
+// The scene's own workspace, grown to `want` bytes of colour records if the device has them, else to what it
+// has (down to `least`): a smaller workspace only means more sample batches, never other bytes.
+int grow_workspace(PtScene* scene, size_t want, size_t least) {
+    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
+    if (scene->rgb_bytes >= want) return PT_OK;
+    if (scene->rgb.p != nullptr) { HIP_TRY(hipFree(scene->rgb.p)); scene->rgb.p = nullptr; scene->rgb_bytes = 0; }
+    size_t free_bytes = 0, total_bytes = 0;
+    HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+    size_t bytes = std::min(want, std::max(least, free_bytes - free_bytes / 8));
+    bytes = least * std::max<size_t>(1, bytes / least);          // whole sample groups
+    for (;;) {
+        const hipError_t e = hipMalloc(&scene->rgb.p, bytes);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        scene->rgb.p = nullptr;
+        if (bytes <= least) return pt::fail(PT_ERR_OUT_OF_MEMORY, "the colour workspace of one sample group (%zu bytes) does not fit the device: %s", least, hipGetErrorString(e));
+        bytes = least * std::max<size_t>(1, bytes / least / 2);
+    }
+    scene->rgb_bytes = bytes;
+    return PT_OK;
 }
 
 // Persistent wavefront path: sample batches sized to the workspace, each batch = trace + ordered sum.
-int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
+int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream, Workspace ws) {
     const Tunables t = tunables();
     const long long tiles_x = (frame->width + 7) / 8;
     const long long real_tiles = local_tiles(*frame);
     const size_t bytes_per_group = static_cast<size_t>(real_tiles) * 4 * CHUNK_PATHS * sizeof(double);
-    const size_t cap = static_cast<size_t>(t.workspace_gb * 1024.0 * 1024.0 * 1024.0);
     const int total_groups = (frame->sample_count + SAMPLES_PER_CHUNK - 1) / SAMPLES_PER_CHUNK;
-    int groups_per_batch = static_cast<int>(std::max<size_t>(1, cap / bytes_per_group));
-    groups_per_batch = std::min(groups_per_batch, total_groups);
-    const size_t need = bytes_per_group * groups_per_batch;
-    if (scene->rgb_bytes < need) {
-        if (scene->rgb.p != nullptr) { HIP_TRY(hipFree(scene->rgb.p)); scene->rgb.p = nullptr; scene->rgb_bytes = 0; }
-        HIP_TRY(hipMalloc(&scene->rgb.p, need));
-        scene->rgb_bytes = need;
+    if (ws.fixed) {
+        if (bytes_per_group > ws.rgb_bytes) {
+            return pt::fail(PT_ERR_UNSUPPORTED, "the frame's rows hold %lld tiles of 8x8 pixels; a launch that may not allocate takes at most %lld "
+                            "(render the frame in several row ranges)", real_tiles, static_cast<long long>(ws.rgb_bytes / (4 * CHUNK_PATHS * sizeof(double))));
+        }
+    } else {
+        const size_t cap = static_cast<size_t>(t.workspace_gb * 1024.0 * 1024.0 * 1024.0);
+        const size_t wanted_groups = std::min<size_t>(std::max<size_t>(1, cap / bytes_per_group), total_groups);
+        const int rc = grow_workspace(scene, bytes_per_group * wanted_groups, bytes_per_group);
+        if (rc != PT_OK) return rc;
+        ws.rgb = static_cast<double*>(scene->rgb.p);
+        ws.rgb_bytes = std::min(scene->rgb_bytes, bytes_per_group * wanted_groups);    // PT_WORKSPACE_GB may ask for less than an earlier call left
+        ws.counters = scene->counters.p;
     }
-    if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
+    const int groups_per_batch = static_cast<int>(std::min<size_t>(ws.rgb_bytes / bytes_per_group, total_groups));
+    scene->last_counters = ws.counters;
     const bool node32 = scene->dev.tri_quads != nullptr && !t.force_f64_nodes;
     // per-lane stack slots: the triangle search's need, and the sphere tree's when it is walked in place
     // (a lane of the 4-wide search that would outgrow its slots falls back to the exhaustive traversal, so
@@ -649,13 +698,13 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         scene->compute_units = prop.multiProcessorCount;
         scene->occupancy_variant = variant;
         int per_cu = 0;
-        const int rc = trace_paths(t.stats, node32, 0, stack_bytes, stream, scene->dev, FrameParams{}, WorkParams{}, nullptr, nullptr, nullptr, &per_cu);
+        const int rc = trace_paths(t.stats, node32, 0, stack_bytes, stream, scene->dev, FrameParams{}, WorkParams{}, TraceOutputs{}, &per_cu);
         if (rc != PT_OK) return rc;
         scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
     }
-    unsigned int* counter = static_cast<unsigned int*>(scene->counters.p);
-    unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(scene->counters.p) + 512);
-    HIP_TRY(hipMemsetAsync(scene->counters.p, 0, 1024, stream));   // the unit counter + profiling counters
+    unsigned int* counter = static_cast<unsigned int*>(ws.counters);
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws.counters) + 512);
+    HIP_TRY(hipMemsetAsync(ws.counters, 0, 1024, stream));   // the unit counter + profiling counters
 
     FrameParams fp = frame_params(*frame);
     const int sample_end = frame->sample_begin + frame->sample_count;
@@ -675,30 +724,44 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.leaf_threshold = t.leaf_threshold;
         wp.stack_slots = stack_slots;
         wp.distrust_mask = t.distrust_mask;
+        wp.export_hits = ws.hit_triangle != nullptr ? 1 : 0;
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
         first = false;
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
                                                                           (units + 3) / 4));
-        const int rc = trace_paths(t.stats, node32, blocks, stack_bytes, stream, scene->dev, fp, wp, static_cast<double*>(scene->rgb.p), counter, stats, nullptr);
+        const int rc = trace_paths(t.stats, node32, blocks, stack_bytes, stream, scene->dev, fp, wp,
+                                   TraceOutputs{ws.rgb, counter, stats, ws.hit_triangle, ws.hit_sphere}, nullptr);
         if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,
-                           fp, wp, static_cast<const double*>(scene->rgb.p), accum_device);
+                           fp, wp, static_cast<const double*>(ws.rgb), accum_device);
         HIP_TRY(hipGetLastError());
     }
     scene->has_stats = t.stats != 0;
     return PT_OK;
 }
 
-int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream) {
+int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream, Workspace ws) {
     if (frame->row_begin == frame->row_end || frame->sample_count == 0 || grid_blocks(*frame) == 0) return PT_OK;
     HIP_TRY(hipSetDevice(scene->device));
+    // A handle owns one work counter, one colour workspace and one pair of timing events: a launch on
+    // another stream while the previous one is still running would share them.  Launches on one stream
+    // are ordered by the stream and need no check.
+    if (scene->timed && stream != scene->last_stream) {
+        const hipError_t previous = hipEventQuery(scene->stop);
+        if (previous == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return pt::fail(PT_ERR_UNSUPPORTED, "the previous launch on this scene handle is still running on another stream: "
+                            "wait for it, use one stream per handle, or create a second handle for overlapping launches");
+        }
+        if (previous != hipSuccess) return pt::fail(PT_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(previous));
+    }
     scene->has_stats = false;
     HIP_TRY(hipEventRecord(scene->start, stream));
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
     const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel &&
                            scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS;
-    const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream) : launch_pixels_kernel(scene, frame, accum_device, stream);
+    const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream, ws) : launch_pixels_kernel(scene, frame, accum_device, stream);
     if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->stop, stream));
     scene->last_stream = stream;
@@ -805,7 +868,7 @@ int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device,
     if (scene == nullptr || accum_device == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_render_device: null argument");
     const int rc = check_frame(frame);
     if (rc != PT_OK) return rc;
-    return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream));
+    return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream), Workspace{});
 }
 
 int pt_tonemap_device(int32_t device, const double* accum_device, int64_t pixel_count, int32_t sample_count, uint8_t* bgra8_device,
@@ -836,7 +899,7 @@ int pt_render(PtScene* scene, const PtFrame* frame, double* accum) {
     DeviceBuffer rows;
     HIP_TRY(hipMalloc(&rows.p, bytes));
     HIP_TRY(hipMemcpy(rows.p, accum + offset, bytes, hipMemcpyHostToDevice));
-    rc = launch_render(scene, frame, static_cast<double*>(rows.p) - offset, nullptr);
+    rc = launch_render(scene, frame, static_cast<double*>(rows.p) - offset, nullptr, Workspace{});
     if (rc != PT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(accum + offset, rows.p, bytes, hipMemcpyDeviceToHost));
@@ -853,12 +916,34 @@ int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_inde
     DeviceBuffer tri, sph;
     HIP_TRY(hipMalloc(&tri.p, pixels * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&sph.p, pixels * sizeof(int32_t)));
-    hipLaunchKernelGGL(primary_hits_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, nullptr, scene->dev, frame_params(*frame),
-                       static_cast<int*>(tri.p), static_cast<int*>(sph.p));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    // rows of the range that belong to another shard keep what the caller's buffers hold
     const size_t offset = static_cast<size_t>(frame->row_begin) * frame->width;
     const size_t count = static_cast<size_t>(frame->row_end - frame->row_begin) * frame->width;
+    if (triangle_index != nullptr) HIP_TRY(hipMemcpy(static_cast<int32_t*>(tri.p) + offset, triangle_index + offset, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (sphere_index != nullptr) HIP_TRY(hipMemcpy(static_cast<int32_t*>(sph.p) + offset, sphere_index + offset, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    // The indices come from the kernel that renders: the persistent wavefront kernel, run over the frame's
+    // rows for one sample and one vertex per path with its two searches kept from shortening each other.
+    // Scenes (and PT_KERNEL=pixels) that render with the one-lane-per-pixel kernel use that kernel's search.
+    const bool wavefront = scene->albedo_bounded && !tunables().force_pixels_kernel &&
+                           scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS;
+    if (wavefront) {
+        PtFrame one = *frame;
+        one.sample_count = 1;
+        one.max_bounces = 1;
+        DeviceBuffer unused_sums;      // the launch also adds the (one-vertex) colours somewhere
+        HIP_TRY(hipMalloc(&unused_sums.p, pixels * 4 * sizeof(double)));
+        Workspace ws;
+        ws.hit_triangle = static_cast<int*>(tri.p);
+        ws.hit_sphere = static_cast<int*>(sph.p);
+        const int launched = launch_render(scene, &one, static_cast<double*>(unused_sums.p), nullptr, ws);
+        if (launched != PT_OK) return launched;
+        HIP_TRY(hipDeviceSynchronize());
+    } else {
+        hipLaunchKernelGGL(primary_hits_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, nullptr, scene->dev, frame_params(*frame),
+                           static_cast<int*>(tri.p), static_cast<int*>(sph.p));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
     if (triangle_index != nullptr) HIP_TRY(hipMemcpy(triangle_index + offset, static_cast<int32_t*>(tri.p) + offset, count * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (sphere_index != nullptr) HIP_TRY(hipMemcpy(sphere_index + offset, static_cast<int32_t*>(sph.p) + offset, count * sizeof(int32_t), hipMemcpyDeviceToHost));
     return PT_OK;
@@ -878,7 +963,7 @@ int pt_last_render_stats(PtScene* scene, uint64_t* out) {
     if (!scene->has_stats) return pt::fail(PT_ERR_UNSUPPORTED, "pt_last_render_stats: the last render did not run the wavefront kernel with PT_STATS=1");
     HIP_TRY(hipSetDevice(scene->device));
     HIP_TRY(hipEventSynchronize(scene->stop));
-    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->counters.p) + 512, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, static_cast<char*>(scene->last_counters) + 512, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -44,6 +44,9 @@ struct WorkParams {
     int stack_slots;             // per-lane stack slots the launch provides in LDS
     int distrust_mask;           // test aid: a winner whose index has none of these bits set is sent to the exhaustive
                                  // traversal as if its box test had failed (negative = never)
+    int export_hits;             // the launch reports each path's first-vertex triangle and sphere index (TraceArgs::hit_*):
+                                 // the two searches then may not shorten each other (the reference runs both in full,
+                                 // src/path_tracing.cpp:177-178, and only then compares, :183)
 };
 
 // rgb layout: [chunk][CHUNK_PATHS][r, g, b, 0] doubles, one 32-byte record per path, written whole
@@ -61,6 +64,8 @@ struct TraceArgs {
     double* rgb;
     unsigned int* next_unit;
     unsigned long long* stats;
+    int* hit_triangle;           // per pixel (row * width + column), written at a path's first vertex; null unless w.export_hits
+    int* hit_sphere;
 };
 // The argument struct behind a pointer the compiler must treat as new at this point: what is read through
 // it is fetched here, by scalar loads, instead of being kept in scalar registers across the whole work
@@ -250,6 +255,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                 } else {
                     resolve_slow_lanes(tie, ray, s.tri_tree, tri_leaf, frames, ht);
                 }
+                if (fetched->w.export_hits != 0 && bounce == 0) {
+                    // `ClosestShapeIntersection.index` of both traversals at the camera ray's vertex (src/path_tracing.cpp:177-178)
+                    const int groups = fetched->w.groups_per_tile, tiles_x = fetched->w.tiles_x;
+                    const int tile = (int)((slot >> 6) / (groups * SAMPLES_PER_CHUNK));
+                    const int tile_row = tile / tiles_x, pixel = (int)(slot & 63);
+                    const int row = f.row_begin + (tile_row * f.shard_count + f.shard_index) * 8 + (pixel >> 3);
+                    const int column = (tile - tile_row * tiles_x) * 8 + (pixel & 7);
+                    const long long at = (long long)row * f.width + column;
+                    fetched->hit_triangle[at] = ht.index;
+                    fetched->hit_sphere[at] = hs.index;
+                }
                 D3 gain;
                 const bool go_on = shade_vertex(scene_for_shading, ray, hs, ht, att, gain);
                 ++bounce;
@@ -368,8 +384,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     best_i = ht.index;
                     best_t = ht.distance;
                 } else if (kind == RAY_FINITE && (NODE32 ? s.search_count : s.tri_tree.count) > 0) {
-                    // a triangle beyond the sphere hit cannot win (:183): the search may stop there
-                    cut = prune_cut(hs.distance);
+                    // a triangle beyond the sphere hit cannot win (:183): the search may stop there (unless the
+                    // launch reports both indices: then the triangle search runs as if there were no sphere)
+                    cut = prune_cut(fetched->w.export_hits != 0 ? REAL_MAX : hs.distance);
                     if (NODE32) {
                         // Every new ray starts at the same node, so it is visited here and now: the lanes all read
                         // the same 128 bytes (one access per load instead of one per lane), and the search needs
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     const double other = is_sphere ? best_t : hs.distance;
                     const bool better = hit & (d < own);
                     const bool equal = hit & (d == own);
-                    const bool closer = better & (d < other);
+                    const bool closer = better & (d < other) & (w.export_hits == 0);    // reporting both indices: nothing is pruned by a hit
                     const double cut_d = prune_cut(d);
                     tie = is_sphere ? tie : ((tie & !better) | equal);
                     tie_s = is_sphere ? ((tie_s & !better) | equal) : tie_s;

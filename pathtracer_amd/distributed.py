@@ -29,6 +29,20 @@ def _rows_on_device(height, rank, world, device):
     return shard_rows(height, rank, world).to(device)
 
 
+def pack_rows(accum, rows, length):
+    """The send buffer of one rank: its rows of `accum` (row indices `rows`, a tensor on accum's device),
+    packed in ascending order into `length` rows (every rank sends the same size; the tail is zero)."""
+    send = torch.zeros((length,) + tuple(accum.shape[1:]), dtype=accum.dtype, device=accum.device)
+    send[: len(rows)] = accum.index_select(0, rows)
+    return send
+
+
+def unpack_rows(accum, rows, received):
+    """Puts the rows another rank packed with `pack_rows` back at their places (`rows`) in `accum`."""
+    accum.index_copy_(0, rows, received[: len(rows)])
+    return accum
+
+
 def gather_rows(accum, height, width, rank, world, dst=0, group=None):
     """accum: (height, width, 4) tensor (float64 sums, or uint8 image) holding this rank's rows
     (others are ignored).  After the call rank `dst` holds every rank's rows in place; other ranks
@@ -37,19 +51,14 @@ def gather_rows(accum, height, width, rank, world, dst=0, group=None):
         return accum
     assert accum.shape == (height, width, 4)
     rows_of = [_rows_on_device(height, r, world, accum.device) for r in range(world)]
-    counts = [len(rows) for rows in rows_of]
-    longest = max(counts)
-    mine = rows_of[rank]
-    send = torch.empty((longest, width, 4), dtype=accum.dtype, device=accum.device)
-    send[: len(mine)] = accum.index_select(0, mine)
-    send[len(mine):] = 0
+    longest = max(len(rows) for rows in rows_of)
+    send = pack_rows(accum, rows_of[rank], longest)
     if rank == dst:
         received = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, received, dst=dst, group=group)
         for r in range(world):
-            if r == dst:
-                continue
-            accum.index_copy_(0, rows_of[r], received[r][: counts[r]])
+            if r != dst:
+                unpack_rows(accum, rows_of[r], received[r])
     else:
         dist.gather(send, None, dst=dst, group=group)
     return accum

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MODELS, same_bits
+from conftest import MODELS, id_hash, same_bits
 from pathtracer_amd import ctypes_abi as abi
 
 pytestmark = pytest.mark.gpu
@@ -56,6 +56,39 @@ def test_every_path_matches_the_checker(api, chess, switches, kernel, nodes, bvh
     switches()
     tri_default, sph_default = api.DeviceScene.from_host(host).primary_hits(frame)
     assert np.array_equal(tri, tri_default) and np.array_equal(sph, sph_default)
+
+
+@pytest.mark.parametrize("bvh", ["sah", "reference"])
+@pytest.mark.parametrize("kernel,nodes", [("wave", "f32"), ("wave", "f64"), ("pixels", "f64")])
+def test_primary_hit_digests_on_every_search(api, golden, switches, kernel, nodes, bvh):
+    """pt_primary_hits reports the first-vertex indices found by the kernel that renders (the persistent
+    wavefront kernel, unless PT_KERNEL=pixels): the reference-made digests of the 600x600 rook frame and the
+    640x360 six-piece frame, and the reference-made 64x36 maps, for each inner-node kind and hierarchy."""
+    switches(PT_KERNEL=kernel, PT_NODES=nodes, PT_BVH=bvh)
+    host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, "rook.triangles"))
+    tri, sph = api.DeviceScene.from_host(host).primary_hits(host.frame(600, 600))
+    assert [(tri >= 0).sum(), id_hash(tri), (sph >= 0).sum()] == golden["rook600_hits"].tolist()
+    host = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
+    device = api.DeviceScene.from_host(host)
+    tri, sph = device.primary_hits(host.frame(640, 360))
+    assert [(tri >= 0).sum(), id_hash(tri), (sph >= 0).sum()] == golden["chess6_640_hits"].tolist()
+    tri, sph = device.primary_hits(host.frame(64, 36))
+    assert np.array_equal(tri, golden["chess6_tri_hits"]) and np.array_equal(sph, golden["chess6_sphere_hits"])
+
+
+def test_primary_hits_of_a_shard_leave_other_rows_alone(api, orc, switches):
+    """Rows outside the frame's range, and rows of the range that another shard owns, keep what the caller's
+    buffers held; a sample other than 0 is reported when sample_begin says so."""
+    host = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
+    device = api.DeviceScene.from_host(host)
+    checker = orc.scene_create(host.arrays())
+    frame = host.frame(90, 61, row_begin=3, row_end=50, sample_begin=7, shard_index=1, shard_count=2)
+    tri, sph = device.primary_hits(frame)
+    tri_c, sph_c = checker.primary_hits(host.frame(90, 61, sample_begin=7))
+    rows = np.arange(61)
+    mine = (rows >= 3) & (rows < 50) & (((rows - 3) // 8) % 2 == 1)
+    assert np.array_equal(tri[mine], tri_c[mine]) and np.array_equal(sph[mine], sph_c[mine])
+    assert (tri[~mine] == -2).all() and (sph[~mine] == -2).all()
 
 
 def test_sample_batches_do_not_change_the_sum(api, chess, switches):
