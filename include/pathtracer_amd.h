@@ -208,6 +208,19 @@ int pt_render(PtScene* scene, const PtFrame* frame, double* accum);
  * PT_ERR_UNSUPPORTED and renders nothing; overlapping frames need one handle each. */
 int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
 
+/* pt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+ * bytes in `accum_device`; the per-path colour records and the work counter live in a workspace that is
+ * part of the library's code object (PT_NOALLOC_MAX_TILES * 32 KiB + 1 KiB of HBM on every GPU the library
+ * is loaded on, held until the process ends), so the call makes no hipMalloc / hipFree.  Limit: the rows the
+ * call renders (its shard of [row_begin, row_end)) may hold at most PT_NOALLOC_MAX_TILES tiles of 8x8 pixels
+ * (524,288 pixels, e.g. 1920 x 272 rows); beyond it PT_ERR_UNSUPPORTED is returned and nothing is rendered
+ * - split the frame into row ranges.  Any sample count is taken (16 samples per pixel pass through the
+ * workspace at a time).  All calls on one GPU share that GPU's workspace, whatever scene handle they go
+ * through: calls that overlap in time on one GPU race; order them on one stream or with events. */
+enum { PT_NOALLOC_MAX_TILES = 8192 };
+int pt_render_device_noalloc(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
+
 /* The tone-map of src/main.cpp:1024-1034 on the GPU: `accum_device` (4*pixel_count
  * doubles) and `bgra8_device` (4*pixel_count bytes) are in the HBM of `device`, the
  * kernel is enqueued on `hip_stream`.  Same bytes as pt_tonemap_bgra8.  Lets a

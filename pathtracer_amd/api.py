@@ -20,7 +20,7 @@ EXPORTS = [
     "pt_construct_sphere_bvh", "pt_rotation_matrix", "pt_look_at_matrix", "pt_camera_look_at", "pt_camera_frame",
     "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8", "pt_tonemap_device",
     "pt_write_pixel_data_file", "pt_write_ppm_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
-    "pt_primary_hits", "pt_last_render_ms", "pt_last_render_stats", "pt_device_eval",
+    "pt_render_device_noalloc", "pt_primary_hits", "pt_last_render_ms", "pt_last_render_stats", "pt_device_eval",
 ]
 
 
@@ -74,6 +74,7 @@ def lib():
         dll.pt_scene_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         dll.pt_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        dll.pt_render_device_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         dll.pt_last_render_stats.argtypes = [C.c_void_p, C.c_void_p]
@@ -252,6 +253,11 @@ class DeviceScene:
         """pt_render_device: accum_device_ptr is a raw HBM address; returns after the launch."""
         check(lib().pt_render_device(self.handle, C.byref(frame), C.c_void_p(accum_device_ptr),
                                      C.c_void_p(stream) if stream else None))
+
+    def render_device_noalloc(self, frame, accum_device_ptr, stream=None):
+        """pt_render_device_noalloc: same as render_device, without any device allocation (bounded frame size)."""
+        check(lib().pt_render_device_noalloc(self.handle, C.byref(frame), C.c_void_p(accum_device_ptr),
+                                             C.c_void_p(stream) if stream else None))
 
     def last_render_ms(self):
         ms = C.c_float()

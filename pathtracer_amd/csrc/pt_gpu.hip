@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "pt_wavefront.hpp"
@@ -204,6 +205,14 @@ __global__ void eval_kernel(int op, const void* __restrict__ in, long long n, vo
 // Host side: flattening, upload, launches
 // =====================================================================================
 
+// Workspace of pt_render_device_noalloc: the unit counter and profiling counters (first
+// STATIC_COUNTER_BYTES) and the per-path colour records behind them.  Every GPU the library runs on holds
+// its own copy of the array, at its own address, until the process ends.  In host code the array's name is
+// only a handle for hipGetSymbolAddress: kernels, memsets and copies are given the address that call returns.
+constexpr size_t STATIC_COUNTER_BYTES = 1024;
+constexpr size_t STATIC_COLOUR_BYTES = size_t(PT_NOALLOC_MAX_TILES) * 4 * CHUNK_PATHS * sizeof(double);   // one sample group of that many tiles
+static __device__ __align__(256) unsigned char scratch[STATIC_COUNTER_BYTES + STATIC_COLOUR_BYTES];
+
 namespace {
 
 #define HIP_TRY(expr)                                                                          \
@@ -217,6 +226,24 @@ struct DeviceBuffer {
     ~DeviceBuffer() { if (p != nullptr) (void)hipFree(p); }
     template <class T> const T* as() const { return static_cast<const T*>(p); }
 };
+
+constexpr int MAX_DEVICES = 64;
+std::mutex static_scratch_lock;
+void* static_scratch_address[MAX_DEVICES] = {};     // per device, resolved once with that device current
+
+// Address of `device`'s copy of the static workspace (the device must be current).
+int static_scratch_of(int device, void** out) {
+    if (device < 0 || device >= MAX_DEVICES) return pt::fail(PT_ERR_UNSUPPORTED, "device %d: the static workspace is tracked for %d devices", device, MAX_DEVICES);
+    std::lock_guard<std::mutex> guard(static_scratch_lock);
+    if (static_scratch_address[device] == nullptr) {
+        void* address = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
+        if (address == nullptr) return pt::fail(PT_ERR_DEVICE, "hipGetSymbolAddress gave no address for the static workspace on device %d", device);
+        static_scratch_address[device] = address;
+    }
+    *out = static_scratch_address[device];
+    return PT_OK;
+}
 
 int upload(DeviceBuffer& buffer, const void* host, size_t bytes) {
     if (bytes == 0) return PT_OK;
@@ -293,6 +320,7 @@ struct PtScene {
     DeviceBuffer rgb, counters;
     size_t rgb_bytes = 0;
     void* last_counters = nullptr;      // counters of the most recent wavefront launch (the scene's own or the static workspace's)
+    void* static_workspace = nullptr;   // this device's copy of the static workspace (pt_render_device_noalloc)
     bool albedo_bounded = false;        // every albedo finite with |albedo| <= 1
     int compute_units = 0, blocks_per_cu = 0, occupancy_variant = -1;
     unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -854,6 +882,8 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
     scene->dev.bg1 = D3{d->background_gradient_end.r, d->background_gradient_end.g, d->background_gradient_end.b};
     HIP_TRY(hipEventCreate(&scene->start));
     HIP_TRY(hipEventCreate(&scene->stop));
+    rc = static_scratch_of(device, &scene->static_workspace);     // this device is current: resolved once per device
+    if (rc != PT_OK) return rc;
     *out = scene.release();
     return PT_OK;
 }
@@ -869,6 +899,24 @@ int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device,
     const int rc = check_frame(frame);
     if (rc != PT_OK) return rc;
     return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream), Workspace{});
+}
+
+int pt_render_device_noalloc(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream) {
+    if (scene == nullptr || accum_device == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_render_device_noalloc: null argument");
+    const int rc = check_frame(frame);
+    if (rc != PT_OK) return rc;
+    if (local_tiles(*frame) > PT_NOALLOC_MAX_TILES) {
+        return pt::fail(PT_ERR_UNSUPPORTED, "pt_render_device_noalloc: the frame's rows hold %lld tiles of 8x8 pixels, the static workspace takes %d "
+                        "(render the frame in several row ranges)", local_tiles(*frame), static_cast<int>(PT_NOALLOC_MAX_TILES));
+    }
+    // the address hipGetSymbolAddress gave for this scene's device when the scene was created
+    unsigned char* const base = static_cast<unsigned char*>(scene->static_workspace);
+    Workspace ws;
+    ws.counters = base;
+    ws.rgb = reinterpret_cast<double*>(base + STATIC_COUNTER_BYTES);
+    ws.rgb_bytes = STATIC_COLOUR_BYTES;
+    ws.fixed = true;
+    return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream), ws);
 }
 
 int pt_tonemap_device(int32_t device, const double* accum_device, int64_t pixel_count, int32_t sample_count, uint8_t* bgra8_device,

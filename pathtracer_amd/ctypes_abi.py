@@ -15,6 +15,7 @@ PT_ERR_OUT_OF_MEMORY = 4
 PT_ERR_UNSUPPORTED = 5
 
 PT_ROW_BLOCK = 8
+PT_NOALLOC_MAX_TILES = 8192
 
 PT_LAMBERTIAN, PT_METAL, PT_DIELECTRIC, PT_DIFFUSE_LIGHT = 0, 1, 2, 3
 
