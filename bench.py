@@ -9,6 +9,16 @@ A step = one full frame: zero the f64 BGRA+count buffer, render every pixel's 25
 (rows dealt in blocks of 8 over the ranks), gather the rows to rank 0.  The scene (BVH,
 triangles, materials) is resident in each GPU's HBM before the timed region.  Rank 0 prints one
 JSON line.  Msamples/s = width * height * spp * steps / seconds / 1e6, whole job.
+
+What the line's `roofline` is.  The dominant kernel (trace_paths_kernel) is priced against the two
+resources north_star names, both from work the kernel EXECUTES:
+  valu  wave-wide vector instructions issued (committed rocprofv3 count per path, profiles/executed_work.json)
+        x 64 lanes x paths of the launch / live kernel time, against SIMDs x 16 lanes x clock;
+  hbm   memory-side bytes of the launch (committed FETCH_SIZE/WRITE_SIZE passes, profiles/hbm_traffic.json)
+        / live kernel time, against the 8 TB/s HBM peak.
+The primary `roofline` is whichever of the two is nearer its peak (the binding one); both are given.  The
+reference's exhaustive traversal would touch far more bytes per sample than this kernel's pruned search;
+that figure is reported apart, as `algorithmic`, and is no fraction of any peak.
 """
 import argparse
 import json
@@ -27,35 +37,50 @@ from pathtracer_amd import api, ctypes_abi as abi  # noqa: E402
 from pathtracer_amd.distributed import gather_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
-FP64_VALU_PEAK_TOPS = 39.3      # 78.6 TFLOP/s vector FP64 counts an FMA as two; the path may not fuse
+CLOCK_GHZ = 2.4                 # max engine clock
+LANES_PER_SIMD = 16             # a 64-wide vector instruction occupies its SIMD for 4 cycles
+SIMDS_PER_CU = 4
 SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
           "grid": abi.PT_SCENE_CHESS_GRID, "spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}
+# bytes the kernel asks the memory hierarchy for, per executed step (what it reads of each record)
+NODE_STEP_BYTES = 112           # six 16-byte plane rows + the four child references of a 128-byte node
+TRIANGLE_TEST_BYTES = 80        # a, ab, ac, n.n of a triangle record
+VERTEX_BYTES = 48 + 32 + 40     # the winner's own box, its unit normal + material index, the material
+PATH_STORE_BYTES = 32           # one colour record per path
+
+
+def table(name, key):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(key)
 
 
 def algorithmic_work(scene, width, height, max_bounces):
-    """Per-sample bytes / f64 ops of the reference's traversal (oracle/count_work.py)."""
-    table = json.load(open(os.path.join(ROOT, "profiles", "algorithmic_work.json")))
+    """Per-sample bytes / f64 ops of the REFERENCE's exhaustive traversal (oracle/count_work.py)."""
+    all_work = json.load(open(os.path.join(ROOT, "profiles", "algorithmic_work.json")))
     key = f"{scene}_{width}x{height}_depth{max_bounces}"
-    if key not in table:
+    if key not in all_work:
         # per-sample work barely depends on resolution; fall back to the scene's entry at another size
-        others = [k for k in sorted(table) if k.startswith(scene + "_") and k.endswith(f"_depth{max_bounces}")]
+        others = [k for k in sorted(all_work) if k.startswith(scene + "_") and k.endswith(f"_depth{max_bounces}")]
         key = others[0] if others else key
-    return table.get(key, {}).get("per_sample"), key
+    return all_work.get(key, {}).get("per_sample"), key
 
 
-def hbm_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (or None)."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    entry = json.load(open(path)).get(workload)
-    return None if entry is None else entry["trace_paths_kernel"]["hbm_bytes_per_launch"]
+def host_threads():
+    """Threads for the CPU leg: the CPUs this process may run on (the GPU box gives a one-GPU job a share of
+    the machine and says so in OMP_NUM_THREADS; os.cpu_count() there counts the whole machine)."""
+    allowed = len(os.sched_getaffinity(0))
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = int(os.environ.get("PT_CPU_THREADS", min(allowed, share) if share > 0 else allowed))
+    return max(1, threads), allowed, share
 
 
 def cpu_baseline(host, width, height, spp, max_bounces):
-    """The CPU renderer on this box's host cores, on a bounded sample of the same frame."""
+    """The CPU renderer on this box's host cores, on a bounded sample of the same frame: all the cores this job
+    has, then one thread on a band of rows."""
     from oracle.bindings import OracleLib, RefLib, have_ref
-    threads = int(os.environ.get("PT_CPU_THREADS", min(16, os.cpu_count() or 1)))
+    threads, allowed, share = host_threads()
     use_ref = have_ref() and max_bounces == 50
     lib = RefLib() if use_ref else OracleLib()
     scene = lib.scene_create(host.arrays())       # builds its own BVH with its own builder
@@ -63,13 +88,62 @@ def cpu_baseline(host, width, height, spp, max_bounces):
     start = time.perf_counter()
     scene.render(frame, threads=threads)
     seconds = time.perf_counter() - start
+    # one thread: every 16th row block of 8 rows, so the band sees the whole picture's mix of rows
+    band_rows = 0
+    start = time.perf_counter()
+    for begin in range(0, height, 128):
+        end = min(begin + 8, height)
+        scene.render(host.frame(width, height, sample_count=spp, max_bounces=max_bounces, row_begin=begin, row_end=end), threads=1)
+        band_rows += end - begin
+    one_seconds = time.perf_counter() - start
     return {
         "value": width * height * spp / seconds / 1e6, "unit": "Msamples/s", "cores": threads,
         "kind": "reference" if use_ref else "port",
+        "one_thread": {"value": width * band_rows * spp / one_seconds / 1e6, "unit": "Msamples/s", "cores": 1,
+                       "sample": f"{band_rows} rows (8 of every 128) x {spp} samples, {one_seconds:.1f} s"},
+        "nproc": os.cpu_count(), "cpus_allowed": allowed, "cpu_share_announced": share or None,
         "sample": f"same scene and camera, full {width}x{height} frame, samples 0..{spp - 1} of each pixel "
-                  f"({width * height * spp / 1e6:.1f} Msamples, {seconds:.1f} s); "
+                  f"({width * height * spp / 1e6:.1f} Msamples, {seconds:.1f} s) on {threads} threads = every CPU this job may use "
+                  f"(the machine has {os.cpu_count()}); "
                   + ("the reference's own sources compiled -O2 with asserts live" if use_ref else "CPU restatement, -O2"),
     }
+
+
+def verify_rows(host, accum, width, height, spp, max_bounces, rows):
+    """Rows of the timed region's output against the CPU checker, bit for bit."""
+    from oracle.bindings import OracleLib
+    checker = OracleLib().scene_create(host.arrays())
+    threads = host_threads()[0]
+    for row in rows:
+        frame = host.frame(width, height, sample_count=spp, max_bounces=max_bounces, row_begin=row, row_end=row + 1)
+        expect = checker.render(frame, threads=threads).reshape(height, width, 4)[row]
+        got = accum[row].cpu().numpy()
+        nan = np.isnan(got)
+        if not (np.array_equal(nan, np.isnan(expect)) and np.array_equal(got[~nan].view(np.uint64), expect[~nan].view(np.uint64))):
+            return False
+    return True
+
+
+def executed_steps(scene, host, width, height, spp, max_bounces, device):
+    """What the kernel does per path, counted by its profiling build (PT_STATS=1) on a few samples of the frame."""
+    buf = torch.zeros((height, width, 4), dtype=torch.float64, device=device)
+    os.environ["PT_STATS"] = "1"
+    try:
+        scene.render_device(host.frame(width, height, sample_count=spp, max_bounces=max_bounces), buf.data_ptr(),
+                            torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+        stats = scene.last_render_stats()
+    except api.PathTracerError:
+        return None           # the scene renders with the one-lane-per-pixel kernel: no phase counters
+    finally:
+        os.environ.pop("PT_STATS", None)
+    paths = max(1, stats["paths"])
+    steps = {"node_steps": stats["node_lanes"] / paths, "triangle_tests": stats["leaf_lanes"] / paths, "vertices": stats["shade_lanes"] / paths}
+    steps["bytes_requested"] = (NODE_STEP_BYTES * steps["node_steps"] + TRIANGLE_TEST_BYTES * steps["triangle_tests"]
+                                + VERTEX_BYTES * steps["vertices"] + PATH_STORE_BYTES)
+    lanes = {k: stats[k + "_lanes"] / max(1, stats[k + "_phases"]) for k in ("node", "leaf", "shade")}
+    return {"per_path": steps, "active_lanes_of_64_per_phase": lanes, "counted_on": f"{spp} samples per pixel of the same frame",
+            "f32_boxes_skipped_that_f64_accepts": stats["unsafe_skips"]}
 
 
 def main():
@@ -84,6 +158,8 @@ def main():
     ap.add_argument("--max-bounces", type=int, default=50)
     ap.add_argument("--grid", type=int, default=5, help="boards per side of --scene grid (5 -> 10.56 M triangles)")
     ap.add_argument("--cpu-spp", type=int, default=8, help="samples per pixel of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--verify-rows", type=int, default=3, help="rows of the timed output compared with the CPU checker afterwards (0 = skip)")
+    ap.add_argument("--stats-spp", type=int, default=16, help="samples per pixel of the executed-work count after the timed region (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -128,7 +204,7 @@ def main():
     start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(scene.last_render_ms())   # HIP events around the kernel on its launch stream
+        kernel_ms.append(scene.last_render_ms())   # HIP events around the kernels on their launch stream
     fence()
     seconds = time.perf_counter() - start
     if world > 1:
@@ -139,33 +215,63 @@ def main():
     if rank == 0:
         samples_per_step = w * h * args.spp
         value = samples_per_step * args.steps / seconds / 1e6
+        workload = f"{scene_name} {w}x{h} {args.spp}spp depth{args.max_bounces}"
+        launch_s = float(np.mean(kernel_ms)) * 1e-3
+        launch_paths = samples_per_step / world            # what one launch (this rank's) processes
+        compute_units = torch.cuda.get_device_properties(device).multi_processor_count
+        valu_peak = compute_units * SIMDS_PER_CU * LANES_PER_SIMD * CLOCK_GHZ * 1e9 / 1e12      # T lane-operations / s
+
+        per_path = table("executed_work.json", workload)             # committed rocprofv3 instruction counts of this workload
+        traffic = table("hbm_traffic.json", workload)
+        hbm_bytes = None if traffic is None else traffic["trace_paths_kernel"]["hbm_bytes_per_launch"] / world
+        valu = hbm = None
+        if per_path is not None:
+            tops = per_path["valu_wave_instructions_per_path"] * 64 * launch_paths / launch_s / 1e12
+            valu = {"bound": "valu", "achieved": tops, "peak": valu_peak, "unit": "Tlane-op/s", "frac": tops / valu_peak,
+                    "basis": f"{per_path['valu_wave_instructions_per_path']:.1f} vector instructions per path (SQ_INSTS_VALU, {per_path['source']}) "
+                             "x 64 lanes x paths / live kernel time; peak = CUs x 4 SIMDs x 16 lanes x 2.4 GHz, every instruction counted as one "
+                             "operation per lane (no fused multiply-add credit: the f64 arithmetic may not fuse)"}
+        if hbm_bytes is not None:
+            gbs = hbm_bytes / launch_s / 1e9
+            hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                   "basis": "FETCH_SIZE (doubled, as 16-byte-per-lane reads are tallied at half) + WRITE_SIZE of the kernel's launch, "
+                            f"separate rocprofv3 --pmc passes ({traffic['source']}) / live kernel time"}
+        candidates = [r for r in (valu, hbm) if r is not None]
+        roofline = {"bound": "valu", "achieved": None, "peak": valu_peak, "unit": "Tlane-op/s", "frac": None}
+        if candidates:
+            roofline = dict(max(candidates, key=lambda r: r["frac"]))
+        roofline.update({"traffic": hbm_bytes, "kernel": "trace_paths_kernel (+ sum_samples_kernel, 2% of the time)", "kernel_ms": launch_s * 1e3,
+                         "paths_per_launch": launch_paths, "valu": valu, "hbm": hbm})
+
         work, work_key = algorithmic_work(scene_name, w, h, args.max_bounces)
-        launch_ms = float(np.mean(kernel_ms))
-        launch_samples = samples_per_step / world            # what one launch (this rank's) processes
-        roofline, valu = None, None
+        executed = executed_steps(scene, host, w, h, args.stats_spp, args.max_bounces, device) if (world == 1 and args.stats_spp > 0) else None
+        algorithmic = None
         if work is not None:
-            gbs = work["bytes"] * launch_samples / (launch_ms * 1e-3) / 1e9
-            workload = f"{scene_name} {w}x{h} {args.spp}spp depth{args.max_bounces}"
-            roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": hbm_traffic(workload) if world == 1 else None,
-                        "kernel": "trace_paths_kernel (+ sum_samples_kernel, <1%)", "kernel_ms": launch_ms,
-                        "algorithmic_bytes_per_sample": work["bytes"], "work_table": work_key}
-            tops = work["f64_ops"] * launch_samples / (launch_ms * 1e-3) / 1e12
-            valu = {"bound": "fp64 valu (no FMA)", "achieved": tops, "peak": FP64_VALU_PEAK_TOPS, "unit": "Tops/s",
-                    "frac": tops / FP64_VALU_PEAK_TOPS, "algorithmic_f64_ops_per_sample": work["f64_ops"]}
+            algorithmic = {"what": "the reference's exhaustive traversal of the same samples (every node whose box passes, both children always), "
+                                   "counted by the CPU checker; NOT work this kernel does and not a fraction of any peak",
+                           "bytes_per_sample": work["bytes"], "f64_ops_per_sample": work["f64_ops"], "node_visits_per_sample": work["node_visits"],
+                           "triangle_tests_per_sample": work["triangle_tests"], "work_table": work_key,
+                           "equivalent_GBps": work["bytes"] * launch_paths / launch_s / 1e9}
+            if executed is not None:
+                algorithmic["bytes_avoided_ratio"] = work["bytes"] / executed["per_path"]["bytes_requested"]
+        if executed is not None:
+            executed["requested_GBps_from_caches"] = executed["per_path"]["bytes_requested"] * launch_paths / launch_s / 1e9
         line = {
             "metric": "Msamples/sec (whole node), chess set 1080p 256spp at 1/2/4/8 MI355X",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64",
             "data": "synthetic: deterministic chess-set scene built from the reference's six .triangles models; no random inputs",
-            "config": {"workload": f"{scene_name} {w}x{h} {args.spp}spp depth{args.max_bounces}",
-                       "triangles": int(host.desc.triangle_count), "width": w, "height": h, "spp": args.spp,
+            "config": {"workload": workload, "triangles": int(host.desc.triangle_count), "width": w, "height": h, "spp": args.spp,
                        "max_bounces": args.max_bounces,
                        "parallelism": f"rows in blocks of 8 round-robin over {world} GPU(s), scene replicated, one gather to rank 0"},
-            "roofline": roofline, "roofline_valu": valu,
+            "roofline": roofline, "executed": executed, "algorithmic": algorithmic,
             "setup_seconds": {"load_and_bvh_build": t1 - t0, "flatten_and_upload": t2 - t1},
         }
+        # the timed region's own output against the CPU checker (rank 0 holds every rank's rows after the gather)
+        rows = sorted({1, h // 2 + 3, h - 2})[: args.verify_rows]
+        line["verified"] = verify_rows(host, accum, w, h, args.spp, args.max_bounces, rows) if rows else None
+        line["verified_rows"] = rows
         if world == 1 and args.cpu_spp > 0:
             line["cpu_baseline"] = cpu_baseline(host, w, h, args.cpu_spp, args.max_bounces)
         print(json.dumps(line), flush=True)
