@@ -40,18 +40,30 @@ namespace {
 
 struct Job { int node, axis, begin, end; };
 
+struct KeyedIndex { double key; int index; };
+
 struct Build {
     const std::vector<PtAabb>& boxes;
     std::vector<int>& order;
     PtBvhNode* nodes;
+    std::vector<KeyedIndex>& keyed;      // as long as `order`: a range is sorted in its own stretch of it
 
+    // std::sort of order[begin, end) by the box minimum on `axis` (src/bvh.cpp:33-38).  The keys are copied next to
+    // the indices first: the comparisons then read consecutive memory instead of boxes all over the array.  What
+    // std::sort does depends only on the outcomes of the comparisons it makes, and those are the same, so the
+    // permutation is the one the reference's call produces (equal keys included).
     void sort_range(int axis, int begin, int end) const {
         const PtAabb* b = boxes.data();
-        int* first = order.data() + begin;
-        int* last = order.data() + end;
-        if (axis == 0) std::sort(first, last, [b](int l, int r) { return b[l].min.x < b[r].min.x; });
-        else if (axis == 1) std::sort(first, last, [b](int l, int r) { return b[l].min.y < b[r].min.y; });
-        else std::sort(first, last, [b](int l, int r) { return b[l].min.z < b[r].min.z; });
+        KeyedIndex* first = keyed.data() + begin;
+        KeyedIndex* last = keyed.data() + end;
+        const int* from = order.data() + begin;
+        for (KeyedIndex* k = first; k != last; ++k, ++from) {
+            const PtVec3& m = b[*from].min;
+            *k = KeyedIndex{axis == 0 ? m.x : (axis == 1 ? m.y : m.z), *from};
+        }
+        std::sort(first, last, [](const KeyedIndex& l, const KeyedIndex& r) { return l.key < r.key; });
+        int* to = order.data() + begin;
+        for (KeyedIndex* k = first; k != last; ++k, ++to) *to = k->index;
     }
 
     // Fills node `self` and its whole subtree; returns nothing, the box is read back from nodes[self].
@@ -122,7 +134,8 @@ void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads) 
     if (count == 0) return;
     std::vector<int> order(count);
     for (int i = 0; i < count; ++i) order[i] = i;
-    Build build{boxes, order, nodes};
+    std::vector<KeyedIndex> keyed(count);
+    Build build{boxes, order, nodes, keyed};
     if (threads <= 1 || count < 1 << 15) {
         build.fill(0, 0, 0, count, nullptr, 0);
         return;

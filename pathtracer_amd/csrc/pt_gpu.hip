@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "pt_wavefront.hpp"
@@ -281,21 +283,21 @@ int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, c
 }
 
 // Reference tree -> PairNode array (inner nodes numbered in pre-order).
-void flatten_tree(const PtBvhNode* nodes, int node_count, std::vector<PairNode>* pairs, int32_t* root_ref) {
+void flatten_tree(const PtBvhNode* nodes, int node_count, std::vector<PairNodeHost>* pairs, int32_t* root_ref) {
     std::vector<int32_t> pair_of(node_count, -1);
     int32_t next = 0;
     for (int i = 0; i < node_count; ++i) {   // the reference numbers nodes in pre-order already
         if (!(nodes[i].left == 0 && nodes[i].right == 0)) pair_of[i] = next++;
     }
-    pairs->assign(next, PairNode{});
+    pairs->assign(next, PairNodeHost{});
     auto ref_of = [&](int node) -> int32_t {
         return (nodes[node].left == 0 && nodes[node].right == 0) ? ~nodes[node].index : pair_of[node];
     };
     for (int i = 0; i < node_count; ++i) {
         if (pair_of[i] < 0) continue;
-        PairNode& p = (*pairs)[pair_of[i]];
-        std::memcpy(p.lbox, &nodes[nodes[i].left].aabb, 48);
-        std::memcpy(p.rbox, &nodes[nodes[i].right].aabb, 48);
+        PairNodeHost& p = (*pairs)[pair_of[i]];
+        p.lbox = nodes[nodes[i].left].aabb;
+        p.rbox = nodes[nodes[i].right].aabb;
         p.left = ref_of(nodes[i].left);
         p.right = ref_of(nodes[i].right);
     }
@@ -303,6 +305,18 @@ void flatten_tree(const PtBvhNode* nodes, int node_count, std::vector<PairNode>*
 }
 
 D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
+
+// PT_VERBOSE=1: seconds since the previous call, printed with what was done in them.
+struct StageClock {
+    const bool on = std::getenv("PT_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void done(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pathtracer_amd: %-46s %.3f s\n", what, std::chrono::duration<double>(now - last).count());
+        last = now;
+    }
+};
 
 }  // namespace
 
@@ -334,13 +348,16 @@ struct PtScene {
 namespace {
 
 int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, DeviceBuffer& pairs_buffer,
-               DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, std::vector<PairNode>* pairs_out, bool rebuild) {
+               DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, std::vector<PairNodeHost>* pairs_out, bool rebuild) {
     int height = 0;
+    StageClock clock;
     int rc = validate_tree(nodes, node_count, primitive_count, what, &height);
+    clock.done("reference tree checked");
     if (rc != PT_OK) return rc;
     if (height > STACK_DEPTH) return pt::fail(PT_ERR_UNSUPPORTED, "%s BVH is %d levels deep; the traversal stack holds %d", what, height, STACK_DEPTH);
-    std::vector<PairNode> local_pairs;
-    std::vector<PairNode>& pairs = pairs_out != nullptr ? *pairs_out : local_pairs;
+    static_assert(sizeof(PairNodeHost) == sizeof(PairNode), "host and device pair nodes must match");
+    std::vector<PairNodeHost> local_pairs;
+    std::vector<PairNodeHost>& pairs = pairs_out != nullptr ? *pairs_out : local_pairs;
     int32_t root = 0;
     bool rebuilt = false;
     if (rebuild && primitive_count > 2) {
@@ -350,12 +367,8 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
         for (int i = 0; i < node_count; ++i) {
             if (nodes[i].left == 0 && nodes[i].right == 0) boxes[nodes[i].index] = nodes[i].aabb;
         }
-        std::vector<PairNodeHost> host_pairs;
         int sah_root = 0, sah_height = 0;
-        static_assert(sizeof(PairNodeHost) == sizeof(PairNode), "host and device pair nodes must match");
-        if (pt::build_sah_pairs(boxes, MAX_SEARCH_HEIGHT, &host_pairs, &sah_root, &sah_height) == PT_OK) {
-            pairs.resize(host_pairs.size());
-            std::memcpy(pairs.data(), host_pairs.data(), host_pairs.size() * sizeof(PairNode));
+        if (pt::build_sah_pairs(boxes, MAX_SEARCH_HEIGHT, &pairs, &sah_root, &sah_height) == PT_OK) {
             root = sah_root;
             height = sah_height;
             rebuilt = true;
@@ -364,11 +377,13 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
         }
     }
     if (!rebuilt) flatten_tree(nodes, node_count, &pairs, &root);
+    clock.done(rebuilt ? "binary search hierarchy built (SAH)" : "reference tree flattened");
     *height_out = height;
     rc = upload(pairs_buffer, pairs.data(), pairs.size() * sizeof(PairNode));
     if (rc != PT_OK) return rc;
     rc = upload(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
     if (rc != PT_OK) return rc;
+    clock.done("pair nodes and reference nodes uploaded");
     tree->pairs = pairs_buffer.as<PairNode>();
     tree->ref_nodes = ref_buffer.as<PtBvhNode>();
     tree->root = root;
@@ -377,77 +392,13 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
     return PT_OK;
 }
 
-float outward_down(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) > x) ? std::nextafterf(f, -INFINITY) : f; }
-float outward_up(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) < x) ? std::nextafterf(f, INFINITY) : f; }
-
-// The binary hierarchy collapsed to four children per node.  A node takes the two children of a
-// pair and then, while a slot is free, replaces its largest inner child by that child's two
-// children.  Numbered in depth-first order; `pending` = stack entries that can be waiting when a
-// node is entered (each ancestor leaves at most its other children behind); `deepest_pending` =
-// the most that can be waiting anywhere in the search.
-struct QuadBuild {
-    std::vector<QuadNode32> nodes;
-    std::vector<QuadBoxes64> exact;
-    int deepest_pending = 0;
-};
-
-double box_half_area(const double* b) {
-    const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
-    return dx * dy + dy * dz + dz * dx;
-}
-
-int collapse_to_quads(const std::vector<PairNode>& pairs, int pair, int pending, QuadBuild* out) {
-    int ref[4];
-    const double* box[4];
-    int n = 2;
-    ref[0] = pairs[pair].left;  box[0] = pairs[pair].lbox;
-    ref[1] = pairs[pair].right; box[1] = pairs[pair].rbox;
-    while (n < 4) {
-        int widest = -1;
-        for (int i = 0; i < n; ++i) {
-            if (ref[i] >= 0 && (widest < 0 || box_half_area(box[i]) > box_half_area(box[widest]))) widest = i;
-        }
-        if (widest < 0) break;
-        const PairNode& inner = pairs[ref[widest]];
-        ref[widest] = inner.left;  box[widest] = inner.lbox;
-        ref[n] = inner.right;      box[n] = inner.rbox;
-        ++n;
-    }
-    const int index = static_cast<int>(out->nodes.size());
-    out->nodes.emplace_back();
-    out->exact.emplace_back();
-    out->deepest_pending = std::max(out->deepest_pending, pending + n - 1);   // entries left behind while a child of this node is searched
-    {
-        QuadNode32& q = out->nodes[index];
-        QuadBoxes64& e = out->exact[index];
-        for (int i = 0; i < 4; ++i) {
-            for (int k = 0; k < 3; ++k) {
-                // an empty slot is all NaN: the kernel's entry test is false for NaN bounds
-                q.plane[k][i] = (i < n) ? outward_down(box[i][k]) : std::nanf("");
-                q.plane[3 + k][i] = (i < n) ? outward_up(box[i][3 + k]) : std::nanf("");
-                e.box[i][k] = (i < n) ? box[i][k] : std::nan("");
-                e.box[i][3 + k] = (i < n) ? box[i][3 + k] : std::nan("");
-            }
-            q.child[i] = (i < n) ? ref[i] : 0;
-            q.pad_[i] = 0;
-        }
-    }
-    for (int i = 0; i < n; ++i) {
-        if (ref[i] >= 0) {
-            const int child = collapse_to_quads(pairs, ref[i], pending + n - 1, out);
-            out->nodes[index].child[i] = child;      // the vector may have grown: index, not a reference
-        }
-    }
-    return index;
-}
-
 // The wavefront kernel's search hierarchy: 4-wide single-precision nodes (boxes rounded outward)
 // and every primitive's own exact box.  `tri_pairs` is the binary hierarchy over the triangles; when
 // the scene has more than one sphere, a binary SAH hierarchy over triangles and spheres together is
 // built here instead, so that one search finds both nearest hits.  Skipped, leaving tri_quads null
 // (the exact-node path then serves the scene), when a coordinate is outside the range in which the
 // f32 slab products are guaranteed finite, or when there is no inner node at all.
-int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pairs, bool reference_topology, PtScene* scene) {
+int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNodeHost>& tri_pairs, bool reference_topology, PtScene* scene) {
     DeviceScene& dev = scene->dev;
     dev.tri_quads = nullptr;
     dev.sphere_base = 0x7fffffff;
@@ -484,22 +435,22 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
     }
     if (d.sphere_count == 1 && !in_range(pt::box_of(d.spheres[0]))) return PT_OK;    // the lone sphere's box is tested by the same kernel
 
-    std::vector<PairNode> merged_pairs;
-    const std::vector<PairNode>* pairs = &tri_pairs;
+    std::vector<PairNodeHost> merged_pairs;
+    const std::vector<PairNodeHost>* pairs = &tri_pairs;
     if (merge) {
-        std::vector<PairNodeHost> host_pairs;
         int root = 0, height = 0;
-        if (pt::build_sah_pairs(own_boxes, MAX_SEARCH_HEIGHT, &host_pairs, &root, &height) != PT_OK) {
+        if (pt::build_sah_pairs(own_boxes, MAX_SEARCH_HEIGHT, &merged_pairs, &root, &height) != PT_OK) {
             pt::clear_error();
             return PT_OK;
         }
-        merged_pairs.resize(host_pairs.size());
-        std::memcpy(merged_pairs.data(), host_pairs.data(), host_pairs.size() * sizeof(PairNode));
         pairs = &merged_pairs;
     }
     if (pairs->empty()) return PT_OK;
-    QuadBuild quads;
-    collapse_to_quads(*pairs, 0, 0, &quads);
+    StageClock clock;
+    static_assert(sizeof(QuadNode32Host) == sizeof(QuadNode32) && sizeof(QuadBoxes64Host) == sizeof(QuadBoxes64), "host and device four-wide nodes must match");
+    QuadHierarchy quads;
+    pt::collapse_to_quads(pairs->data(), pairs->size(), &quads);
+    clock.done("collapsed to four-wide nodes");
     if (quads.nodes.size() > (size_t(1) << 25)) return PT_OK;   // the kernel addresses a node by a 32-bit byte offset
     scene->tri_stack_need = quads.deepest_pending + 4;      // a visit writes four slots above the pending entries
     if (std::getenv("PT_VERBOSE") != nullptr) {
@@ -519,6 +470,7 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNode>& tri_pa
     if (rc != PT_OK) return rc;
     rc = upload(scene->tri_leaf_boxes, leaf_boxes.data(), leaf_boxes.size() * sizeof(LeafBox));
     if (rc != PT_OK) return rc;
+    clock.done("four-wide nodes, exact boxes, leaf boxes uploaded");
     dev.tri_quads = scene->tri_quads.as<QuadNode32>();
     dev.tri_quad_boxes = scene->tri_quad_boxes.as<QuadBoxes64>();
     dev.tri_boxes = scene->tri_leaf_boxes.as<LeafBox>();
@@ -828,32 +780,42 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
     std::unique_ptr<PtScene> scene(new PtScene());
     scene->device = device;
     int rc;
-    std::vector<PairNode> pairs;
+    std::vector<PairNodeHost> pairs;
     if (d->triangle_count > 0) {
         rc = build_tree(d->triangle_bvh, d->triangle_bvh_node_count, d->triangle_count, "triangle", scene->tri_pairs, scene->tri_ref_nodes,
                         &scene->dev.tri_tree, &scene->tri_height, &pairs, !tunables().reference_topology);
         if (rc != PT_OK) return rc;
         // ray-independent part of the triangle test, same operations as src/geometry.cpp:111-114, :124, :84-90
+        StageClock clock;
         std::vector<TriRecord> records(d->triangle_count);
-        for (int i = 0; i < d->triangle_count; ++i) {
-            const PtTriangle& t = d->triangles[i];
-            using namespace pt;
-            const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
-            const PtVec3 n = cross(ab, ac);
-            const double nn = dot(n, n);
-            const PtVec3 un = (1.0f / std::sqrt(nn)) * n;
-            TriRecord& r = records[i];
-            r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
-            r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
-            r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
-            r.nn = nn;
-            r.un[0] = un.x; r.un[1] = un.y; r.un[2] = un.z;
-            r.material = d->triangle_material_indices[i];
-            for (int32_t& unused : r.pad_) unused = 0;
+        const int threads = pt::host_threads();
+        std::vector<std::thread> team;
+        for (int part = 0; part < threads; ++part) {
+            team.emplace_back([&, part]() {
+                const long long n = d->triangle_count;
+                for (long long i = n * part / threads; i < n * (part + 1) / threads; ++i) {
+                    const PtTriangle& t = d->triangles[i];
+                    using namespace pt;
+                    const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
+                    const PtVec3 n3 = cross(ab, ac);
+                    const double nn = dot(n3, n3);
+                    const PtVec3 un = (1.0f / std::sqrt(nn)) * n3;
+                    TriRecord& r = records[i];
+                    r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
+                    r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
+                    r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
+                    r.nn = nn;
+                    r.un[0] = un.x; r.un[1] = un.y; r.un[2] = un.z;
+                    r.material = d->triangle_material_indices[i];
+                    for (int32_t& unused : r.pad_) unused = 0;
+                }
+            });
         }
+        for (std::thread& t : team) t.join();
         rc = upload(scene->tri_records, records.data(), records.size() * sizeof(TriRecord));
         if (rc != PT_OK) return rc;
         scene->dev.tris = scene->tri_records.as<TriRecord>();
+        clock.done("triangle records made and uploaded");
     }
     if (d->sphere_count > 0) {
         rc = build_tree(d->sphere_bvh, d->sphere_bvh_node_count, d->sphere_count, "sphere", scene->sph_pairs, scene->sph_ref_nodes,

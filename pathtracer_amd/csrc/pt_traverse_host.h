@@ -18,14 +18,38 @@ struct PairNodeHost {
 };
 static_assert(sizeof(PairNodeHost) == 128, "PairNodeHost mirrors PairNode");
 
+// Same 128 bytes as the device's QuadNode32 (four children: six bounds each, single precision, rounded
+// outward; an empty slot holds NaN bounds and child 0), and the exact boxes beside it (QuadBoxes64).
+struct QuadNode32Host {
+    float plane[6][4];
+    int32_t child[4];      // >= 0: quad index, < 0: ~primitive
+    int32_t pad_[4];
+};
+static_assert(sizeof(QuadNode32Host) == 128, "QuadNode32Host mirrors QuadNode32");
+struct QuadBoxes64Host { double box[4][6]; };
+
+struct QuadHierarchy {
+    std::vector<QuadNode32Host> nodes;      // node 0 is the root
+    std::vector<QuadBoxes64Host> exact;
+    int deepest_pending = 0;                // the most stack entries that can be waiting anywhere in a search
+};
+
 }  // namespace ptd
 
 namespace pt {
+
+int host_threads();
 
 // Surface-area-heuristic hierarchy over `boxes` (one primitive per leaf, pre-order pair
 // numbering, height <= max_height).  *root_ref is a child reference (~0 for a single box).
 int build_sah_pairs(const std::vector<PtAabb>& boxes, int max_height, std::vector<ptd::PairNodeHost>* pairs, int* root_ref,
                     int* height_out);
+
+
+// The binary hierarchy `pairs` (root = pair 0) collapsed to four children per node: a node takes the two
+// children of a pair and then, while a slot is free, replaces its largest inner child by that child's two.
+// Built by several threads; the result does not depend on how many.
+void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::QuadHierarchy* out);
 
 }  // namespace pt
 

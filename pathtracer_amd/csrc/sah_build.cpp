@@ -14,6 +14,7 @@
 // balanced subtrees within the remaining levels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -45,33 +46,67 @@ inline int levels_for(int count) {      // height of a balanced tree over `count
     return levels;
 }
 
+// f(lo, hi, part) over [begin, end) cut into `parts` contiguous pieces, one thread each (the caller's included).
+template <class F>
+void in_parts(int begin, int end, int parts, F f) {
+    if (parts <= 1) { f(begin, end, 0); return; }
+    std::vector<std::thread> team;
+    const long long count = end - begin;
+    for (int t = 1; t < parts; ++t) {
+        team.emplace_back([=, &f]() { f(begin + static_cast<int>(count * t / parts), begin + static_cast<int>(count * (t + 1) / parts), t); });
+    }
+    f(begin, begin + static_cast<int>(count / parts), 0);
+    for (std::thread& t : team) t.join();
+}
+
+constexpr int TEAM_MINIMUM = 1 << 18;     // ranges at least this long are binned and partitioned by several threads
+
+struct Bins {
+    PtAabb box[3][BINS];
+    int count[3][BINS];
+    Bins() {
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) { box[a][b] = empty_box(); count[a][b] = 0; }
+    }
+};
+
 struct Builder {
     const std::vector<PtAabb>& boxes;
     std::vector<PtVec3> centroids;
     std::vector<int> order;
+    std::vector<int> spare;              // partition buffer of the ranges that several threads split together
     ptd::PairNodeHost* pairs;
     int max_height;
 
     // Builds the subtree over order[begin, end) whose root pair (if any) is pairs[node];
     // `level` is the depth of that root (tree root = 1).  Returns the child reference and box.
-    int build(int begin, int end, int node, int level, int spawn_budget, PtAabb* box_out) {
+    // `threads` = how many threads this subtree may use: for its own split while it is long, then shared out
+    // between its two sides.  The tree does not depend on it: every split is a function of the range as a set.
+    int build(int begin, int end, int node, int level, int threads, PtAabb* box_out) {
         const int count = end - begin;
         if (count == 1) {
             *box_out = boxes[order[begin]];
             return ~order[begin];
         }
+        const int team = (count >= TEAM_MINIMUM) ? threads : 1;
+        std::vector<PtAabb> part_bounds(team, empty_box());
+        in_parts(begin, end, team, [&](int lo, int hi, int part) {
+            PtAabb b = empty_box();
+            for (int i = lo; i < hi; ++i) {
+                const PtVec3& c = centroids[order[i]];
+                grow(b, PtAabb{c, c});
+            }
+            part_bounds[part] = b;
+        });
         PtAabb centroid_bounds = empty_box();
-        for (int i = begin; i < end; ++i) {
-            const PtVec3& c = centroids[order[i]];
-            grow(centroid_bounds, PtAabb{c, c});
-        }
-        const int mid = choose_split(begin, end, level, centroid_bounds);
+        for (const PtAabb& b : part_bounds) grow(centroid_bounds, b);
+        const int mid = choose_split(begin, end, level, centroid_bounds, team);
         const int left_count = mid - begin;
         PtAabb left_box, right_box;
         int left_ref, right_ref;
-        if (spawn_budget > 1 && count > 65536) {
-            std::thread other([&]() { left_ref = build(begin, mid, node + 1, level + 1, spawn_budget / 2, &left_box); });
-            right_ref = build(mid, end, node + left_count, level + 1, spawn_budget - spawn_budget / 2, &right_box);
+        if (threads > 1 && count > 65536) {
+            const int left_threads = std::max(1, std::min(threads - 1, static_cast<int>(static_cast<long long>(threads) * left_count / count)));
+            std::thread other([&]() { left_ref = build(begin, mid, node + 1, level + 1, left_threads, &left_box); });
+            right_ref = build(mid, end, node + left_count, level + 1, threads - left_threads, &right_box);
             other.join();
         } else {
             left_ref = build(begin, mid, node + 1, level + 1, 1, &left_box);
@@ -87,8 +122,13 @@ struct Builder {
         return node;
     }
 
+    static int bin_of(double centroid, double lo, double scale) {
+        const int b = static_cast<int>((centroid - lo) * scale);
+        return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+    }
+
     // Partitions order[begin, end) and returns the split position (begin < mid < end).
-    int choose_split(int begin, int end, int level, const PtAabb& cb) {
+    int choose_split(int begin, int end, int level, const PtAabb& cb, int team) {
         const int count = end - begin;
         const int levels_left = max_height - level;     // levels available below this node's children level
         // a side of m leaves needs levels_for(m) levels starting at level + 1
@@ -96,21 +136,41 @@ struct Builder {
 
         int best_axis = -1, best_bin = -1;
         double best_cost = INFINITY;
+        double lo[3], scale[3];
+        bool open[3];
+        for (int axis = 0; axis < 3; ++axis) {
+            lo[axis] = axis_of(cb.min, axis);
+            const double hi = axis_of(cb.max, axis);
+            open[axis] = hi > lo[axis];
+            scale[axis] = open[axis] ? BINS / (hi - lo[axis]) : 0.0;
+        }
         if (count > 2) {
-            for (int axis = 0; axis < 3; ++axis) {
-                const double lo = axis_of(cb.min, axis), hi = axis_of(cb.max, axis);
-                if (!(hi > lo)) continue;
-                const double scale = BINS / (hi - lo);
-                PtAabb bin_box[BINS];
-                int bin_count[BINS] = {};
-                for (PtAabb& b : bin_box) b = empty_box();
-                for (int i = begin; i < end; ++i) {
+            // all three axes in one pass over the range (bin boxes and counts are unions and sums: whoever
+            // forms them, in whatever order, gets the same)
+            std::vector<Bins> part_bins(team);
+            in_parts(begin, end, team, [&](int from, int to, int part) {
+                Bins& mine = part_bins[part];
+                for (int i = from; i < to; ++i) {
                     const int id = order[i];
-                    int b = static_cast<int>((axis_of(centroids[id], axis) - lo) * scale);
-                    b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                    ++bin_count[b];
-                    grow(bin_box[b], boxes[id]);
+                    const PtVec3& c = centroids[id];
+                    const PtAabb& box = boxes[id];
+                    const int bx = bin_of(c.x, lo[0], scale[0]), by = bin_of(c.y, lo[1], scale[1]), bz = bin_of(c.z, lo[2], scale[2]);
+                    ++mine.count[0][bx]; grow(mine.box[0][bx], box);
+                    ++mine.count[1][by]; grow(mine.box[1][by], box);
+                    ++mine.count[2][bz]; grow(mine.box[2][bz], box);
                 }
+            });
+            Bins& all = part_bins[0];
+            for (int part = 1; part < team; ++part) {
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) {
+                    all.count[a][b] += part_bins[part].count[a][b];
+                    grow(all.box[a][b], part_bins[part].box[a][b]);
+                }
+            }
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!open[axis]) continue;
+                const PtAabb* bin_box = all.box[axis];
+                const int* bin_count = all.count[axis];
                 double right_area[BINS];
                 int right_count[BINS];
                 PtAabb acc = empty_box();
@@ -136,14 +196,32 @@ struct Builder {
         int* first = order.data() + begin;
         int* last = order.data() + end;
         if (best_axis >= 0) {
-            const double lo = axis_of(cb.min, best_axis), hi = axis_of(cb.max, best_axis);
-            const double scale = BINS / (hi - lo);
-            int* middle = std::partition(first, last, [&](int id) {
-                int b = static_cast<int>((axis_of(centroids[id], best_axis) - lo) * scale);
-                b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                return b <= best_bin;
+            const double axis_lo = lo[best_axis], axis_scale = scale[best_axis];
+            auto goes_left = [&](int id) { return bin_of(axis_of(centroids[id], best_axis), axis_lo, axis_scale) <= best_bin; };
+            if (team <= 1) {
+                int* middle = std::partition(first, last, goes_left);
+                return begin + static_cast<int>(middle - first);
+            }
+            // several threads: each counts its piece's left side, then copies its piece to its places in `spare`
+            std::vector<int> lefts(team + 1, 0), piece_begin(team + 1, end);
+            in_parts(begin, end, team, [&](int from, int to, int part) {
+                int n = 0;
+                for (int i = from; i < to; ++i) n += goes_left(order[i]) ? 1 : 0;
+                lefts[part + 1] = n;
+                piece_begin[part] = from;
             });
-            return begin + static_cast<int>(middle - first);
+            for (int part = 0; part < team; ++part) lefts[part + 1] += lefts[part];
+            const int total_left = lefts[team];
+            in_parts(begin, end, team, [&](int from, int to, int part) {
+                int l = begin + lefts[part];
+                int r = begin + total_left + (from - begin) - lefts[part];
+                for (int i = from; i < to; ++i) {
+                    const int id = order[i];
+                    if (goes_left(id)) spare[l++] = id; else spare[r++] = id;
+                }
+            });
+            in_parts(begin, end, team, [&](int from, int to, int) { std::copy(spare.begin() + from, spare.begin() + to, order.begin() + from); });
+            return begin + total_left;
         }
         // no acceptable binned split (coincident centroids, or the height cap): halve on the widest axis
         int axis = 0;
@@ -160,21 +238,28 @@ struct Builder {
 
 }  // namespace
 
+// Threads the host-side builders use: the machine's, at most 16 (PT_BUILD_THREADS overrides; results do not depend on it).
+int host_threads() {
+    if (const char* v = std::getenv("PT_BUILD_THREADS")) return std::max(1, std::atoi(v));
+    return static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+}
+
 int build_sah_pairs(const std::vector<PtAabb>& boxes, int max_height, std::vector<ptd::PairNodeHost>* pairs, int* root_ref,
                     int* height_out) {
     const int count = static_cast<int>(boxes.size());
     if (count == 0) return fail(PT_ERR_INVALID_ARGUMENT, "build_sah_pairs: no boxes");
     if (levels_for(count) > max_height) return fail(PT_ERR_UNSUPPORTED, "%d leaves cannot fit a tree of height %d", count, max_height);
-    pairs->assign(count > 1 ? count - 1 : 0, ptd::PairNodeHost{});
-    Builder b{boxes, {}, {}, pairs->data(), max_height};
+    pairs->resize(count > 1 ? count - 1 : 0);      // every pair is written in full by build()
+    Builder b{boxes, {}, {}, {}, pairs->data(), max_height};
     b.centroids.resize(count);
     b.order.resize(count);
+    if (count >= TEAM_MINIMUM) b.spare.resize(count);
     for (int i = 0; i < count; ++i) {
         b.centroids[i] = PtVec3{0.5 * (boxes[i].min.x + boxes[i].max.x), 0.5 * (boxes[i].min.y + boxes[i].max.y),
                                 0.5 * (boxes[i].min.z + boxes[i].max.z)};
         b.order[i] = i;
     }
-    const int threads = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    const int threads = host_threads();
     PtAabb root_box;
     *root_ref = b.build(0, count, 0, 1, threads, &root_box);
     // measured height (root pair = level 1, its leaf children = level 2, ...)
@@ -193,6 +278,128 @@ int build_sah_pairs(const std::vector<PtAabb>& boxes, int max_height, std::vecto
     }
     *height_out = height;
     return PT_OK;
+}
+
+namespace {
+
+float outward_down(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) > x) ? std::nextafterf(f, -INFINITY) : f; }
+float outward_up(double x) { const float f = static_cast<float>(x); return (static_cast<double>(f) < x) ? std::nextafterf(f, INFINITY) : f; }
+const double* bounds(const PtAabb& b) { return &b.min.x; }
+double half_area_of(const double* b) {
+    const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// A subtree left for a worker thread: its pair, the entries waiting above it, and where its root's index goes.
+struct QuadTask { int pair; int pending; int parent; int slot; };
+
+struct Collapser {
+    const ptd::PairNodeHost* pairs;
+    const std::vector<int>* leaves_below;     // per pair; null while a worker collapses its whole subtree
+    int task_leaves;                          // subtrees with at most this many leaves become tasks
+    std::vector<QuadTask>* tasks;
+
+    // Appends the four-wide node of `pair` (and, recursively, of its inner children) to `out`; returns its index there.
+    // `pending` = stack entries that can be waiting when the node is entered (each ancestor leaves at most its other
+    // children behind).
+    int collapse(int pair, int pending, ptd::QuadHierarchy* out) const {
+        int ref[4];
+        const double* box[4];
+        int n = 2;
+        ref[0] = pairs[pair].left;  box[0] = bounds(pairs[pair].lbox);
+        ref[1] = pairs[pair].right; box[1] = bounds(pairs[pair].rbox);
+        while (n < 4) {
+            int widest = -1;
+            for (int i = 0; i < n; ++i) {
+                if (ref[i] >= 0 && (widest < 0 || half_area_of(box[i]) > half_area_of(box[widest]))) widest = i;
+            }
+            if (widest < 0) break;
+            const ptd::PairNodeHost& inner = pairs[ref[widest]];
+            ref[widest] = inner.left;  box[widest] = bounds(inner.lbox);
+            ref[n] = inner.right;      box[n] = bounds(inner.rbox);
+            ++n;
+        }
+        const int index = static_cast<int>(out->nodes.size());
+        out->nodes.emplace_back();
+        out->exact.emplace_back();
+        out->deepest_pending = std::max(out->deepest_pending, pending + n - 1);   // entries left behind while a child of this node is searched
+        {
+            ptd::QuadNode32Host& q = out->nodes[index];
+            ptd::QuadBoxes64Host& e = out->exact[index];
+            for (int i = 0; i < 4; ++i) {
+                for (int k = 0; k < 3; ++k) {
+                    // an empty slot is all NaN: the kernel's entry test is false for NaN bounds
+                    q.plane[k][i] = (i < n) ? outward_down(box[i][k]) : std::nanf("");
+                    q.plane[3 + k][i] = (i < n) ? outward_up(box[i][3 + k]) : std::nanf("");
+                    e.box[i][k] = (i < n) ? box[i][k] : std::nan("");
+                    e.box[i][3 + k] = (i < n) ? box[i][3 + k] : std::nan("");
+                }
+                q.child[i] = (i < n) ? ref[i] : 0;
+                q.pad_[i] = 0;
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            if (ref[i] < 0) continue;
+            if (leaves_below != nullptr && (*leaves_below)[ref[i]] <= task_leaves) {
+                tasks->push_back(QuadTask{ref[i], pending + n - 1, index, i});
+                continue;
+            }
+            const int child = collapse(ref[i], pending + n - 1, out);
+            out->nodes[index].child[i] = child;      // the vector may have grown: index, not a reference
+        }
+        return index;
+    }
+};
+
+}  // namespace
+
+void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::QuadHierarchy* out) {
+    out->nodes.clear();
+    out->exact.clear();
+    out->deepest_pending = 0;
+    if (pair_count == 0) return;
+    const int threads = host_threads();
+    if (threads <= 1 || pair_count < (size_t(1) << 16)) {
+        Collapser{pairs, nullptr, 0, nullptr}.collapse(0, 0, out);
+        return;
+    }
+    // leaves below every pair: children are numbered after their parent
+    std::vector<int> leaves_below(pair_count);
+    for (size_t i = pair_count; i-- > 0;) {
+        const ptd::PairNodeHost& p = pairs[i];
+        leaves_below[i] = (p.left < 0 ? 1 : leaves_below[p.left]) + (p.right < 0 ? 1 : leaves_below[p.right]);
+    }
+    // The top of the tree here; subtrees of at most 1/64 of the leaves are left as tasks, collapsed by the threads
+    // into arrays of their own (indices from 0) and appended in the order they were met, so that the layout is the
+    // same whatever the number of threads.
+    std::vector<QuadTask> tasks;
+    Collapser{pairs, &leaves_below, std::max(1024, static_cast<int>((pair_count + 1) / 64)), &tasks}.collapse(0, 0, out);
+    std::vector<ptd::QuadHierarchy> parts(tasks.size());
+    in_parts(0, static_cast<int>(tasks.size()), std::min<int>(threads, static_cast<int>(tasks.size())), [&](int, int, int part) {
+        // tasks are dealt round-robin: neighbouring subtrees differ in size less than far ones
+        const int stride = std::min<int>(threads, static_cast<int>(tasks.size()));
+        for (size_t t = part; t < tasks.size(); t += stride) Collapser{pairs, nullptr, 0, nullptr}.collapse(tasks[t].pair, tasks[t].pending, &parts[t]);
+    });
+    std::vector<size_t> first(tasks.size() + 1, out->nodes.size());
+    for (size_t t = 0; t < tasks.size(); ++t) first[t + 1] = first[t] + parts[t].nodes.size();
+    out->nodes.resize(first[tasks.size()]);
+    out->exact.resize(first[tasks.size()]);
+    for (size_t t = 0; t < tasks.size(); ++t) {
+        out->nodes[tasks[t].parent].child[tasks[t].slot] = static_cast<int32_t>(first[t]);
+        out->deepest_pending = std::max(out->deepest_pending, parts[t].deepest_pending);
+    }
+    in_parts(0, static_cast<int>(tasks.size()), std::min<int>(threads, static_cast<int>(tasks.size())), [&](int, int, int part) {
+        const int stride = std::min<int>(threads, static_cast<int>(tasks.size()));
+        for (size_t t = part; t < tasks.size(); t += stride) {
+            const int32_t offset = static_cast<int32_t>(first[t]);
+            for (size_t i = 0; i < parts[t].nodes.size(); ++i) {
+                ptd::QuadNode32Host q = parts[t].nodes[i];
+                for (int32_t& c : q.child) c = (c > 0) ? c + offset : c;      // a subtree's own root (0) is never a child
+                out->nodes[first[t] + i] = q;
+                out->exact[first[t] + i] = parts[t].exact[i];
+            }
+        }
+    });
 }
 
 }  // namespace pt

@@ -19,7 +19,7 @@ import time
 t0 = time.time()
 dev = api.DeviceScene.from_host(host)
 create_seconds = time.time() - t0
-w, h = 1920, 1080
+w, h = (int(v) for v in os.environ.get("PT_SIZE", "1920x1080").split("x"))
 buf = torch.zeros(4 * w * h, dtype=torch.float64, device="cuda:0")
 fr = host.frame(w, h, sample_count=spp, max_bounces=bounces)
 all_ms = []
