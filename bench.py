@@ -169,18 +169,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PT_DIST_BACKEND=gloo rehearses the N-rank path where fewer GPUs than ranks exist (ranks share GPUs, the gather
+    # goes through host memory): it exercises this script's sharding, timing and gather, not the interconnect.
+    backend = os.environ.get("PT_DIST_BACKEND", "nccl")
+    local_device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_device)
+    device = torch.device("cuda", local_device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- set-up, not timed: load models, build the BVH on the host, upload to HBM
     t0 = time.perf_counter()
     host = api.HostScene(SCENES[args.scene], api.MODELS_DIR, args.grid if args.scene == "grid" else 0)
     scene_name = f"grid{args.grid}" if args.scene == "grid" else args.scene
     t1 = time.perf_counter()
-    scene = api.DeviceScene.from_host(host, device=local_rank)
+    scene = api.DeviceScene.from_host(host, device=local_device)
     t2 = time.perf_counter()
     w, h = args.width, args.height
     frame = host.frame(w, h, sample_count=args.spp, max_bounces=args.max_bounces, shard_index=rank, shard_count=world)
@@ -190,7 +197,12 @@ def main():
     def step():
         accum.zero_()
         scene.render_device(frame, accum.data_ptr(), stream)
-        gather_rows(accum, h, w, rank, world)
+        if backend == "nccl" or world == 1:
+            gather_rows(accum, h, w, rank, world)
+        else:
+            staged = gather_rows(accum.cpu(), h, w, rank, world)
+            if rank == 0:
+                accum.copy_(staged)
 
     def fence():
         if world > 1:
@@ -208,7 +220,7 @@ def main():
     fence()
     seconds = time.perf_counter() - start
     if world > 1:
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        t = torch.tensor([seconds], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
 
@@ -264,7 +276,8 @@ def main():
             "data": "synthetic: deterministic chess-set scene built from the reference's six .triangles models; no random inputs",
             "config": {"workload": workload, "triangles": int(host.desc.triangle_count), "width": w, "height": h, "spp": args.spp,
                        "max_bounces": args.max_bounces,
-                       "parallelism": f"rows in blocks of 8 round-robin over {world} GPU(s), scene replicated, one gather to rank 0"},
+                       "parallelism": f"rows in blocks of 8 round-robin over {world} GPU(s), scene replicated, one gather to rank 0"
+                                      + ("" if backend == "nccl" or world == 1 else f" (rehearsal: {backend}, ranks share GPUs)")},
             "roofline": roofline, "executed": executed, "algorithmic": algorithmic,
             "setup_seconds": {"load_and_bvh_build": t1 - t0, "flatten_and_upload": t2 - t1},
         }

@@ -81,3 +81,30 @@ def test_a_second_launch_on_a_busy_handle_from_another_stream_is_refused(api):
     device.render_device(frame, b.data_ptr(), second.cuda_stream)     # the handle is idle now
     torch.cuda.synchronize()
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+
+
+def test_bench_script_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on
+    one GPU: both ranks render their row blocks on cuda:0 and the gather goes through gloo.  What is checked is
+    the script's N-rank path: sharding by rank, the gather to rank 0, the barrier-bracketed timing and the one
+    JSON line, whose frame must equal the CPU checker's on the verified rows."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PT_DIST_BACKEND="gloo")
+    done = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           "--spp", "16", "--width", "640", "--height", "360"],
+                          capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [line for line in done.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["verified"] is True
+    assert line["value"] > 0 and line["unit"] == "Msamples/s" and line["scaling"] == "strong"
+    assert line["roofline"]["paths_per_launch"] == 640 * 360 * 16 / 2
