@@ -167,6 +167,22 @@ def test_4k_frame_in_batches_and_shards(scenes, switches):
     assert torch.equal(once.view(torch.int64), sharded.view(torch.int64))
 
 
+def test_one_shard_of_the_8_gpu_configuration_in_full(scenes):
+    """What one of 8 GPUs renders of the 3840x2160, 1024-samples-per-pixel frame (its row blocks, every sample: 64 sample
+    groups through the workspace), on three of its rows against the CPU checker; rows of other shards stay untouched."""
+    import torch
+    host, device, checker = scenes("chess32")
+    w, h, spp, index, count = 3840, 2160, 1024, 5, 8
+    image = render_on_device(device, host.frame(w, h, sample_count=spp, shard_index=index, shard_count=count))
+    owner = owner_of_rows(h, count)
+    mine = torch.from_numpy(owner == index).to("cuda:0")
+    assert bool((image[mine][..., 3] == float(spp)).all()) and bool((image[~mine] == 0).all()) and bool(torch.isfinite(image).all())
+    for row in (40, 1128, 2152):
+        assert owner[row] == index
+        expect = checker.render(host.frame(w, h, sample_count=spp, row_begin=row, row_end=row + 1), threads=16)
+        assert same_bits(image[row].cpu().numpy(), expect.reshape(h, w, 4)[row])
+
+
 def test_benchmark_frame_at_256_samples_against_the_checker(scenes):
     """The frame bench.py times (1920x1080, 256 samples per pixel: 16 sample groups dealt across draws) on
     three rows against the CPU checker, every double; count channel and finiteness on the whole frame."""
