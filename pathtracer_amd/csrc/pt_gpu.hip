@@ -306,6 +306,12 @@ void flatten_tree(const PtBvhNode* nodes, int node_count, std::vector<PairNodeHo
 
 D3 d3(const PtVec3& v) { return D3{v.x, v.y, v.z}; }
 
+// Levels the rebuilt binary hierarchy is kept to (PT_SEARCH_HEIGHT overrides; at most what the traversal stacks hold).
+int search_height_cap() {
+    if (const char* v = std::getenv("PT_SEARCH_HEIGHT")) return std::min(static_cast<int>(STACK_DEPTH), std::max(2, std::atoi(v)));
+    return MAX_SEARCH_HEIGHT;
+}
+
 // PT_VERBOSE=1: seconds since the previous call, printed with what was done in them.
 struct StageClock {
     const bool on = std::getenv("PT_VERBOSE") != nullptr;
@@ -368,7 +374,7 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
             if (nodes[i].left == 0 && nodes[i].right == 0) boxes[nodes[i].index] = nodes[i].aabb;
         }
         int sah_root = 0, sah_height = 0;
-        if (pt::build_sah_pairs(boxes, MAX_SEARCH_HEIGHT, &pairs, &sah_root, &sah_height) == PT_OK) {
+        if (pt::build_sah_pairs(boxes, search_height_cap(), &pairs, &sah_root, &sah_height) == PT_OK) {
             root = sah_root;
             height = sah_height;
             rebuilt = true;
@@ -439,7 +445,7 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNodeHost>& tr
     const std::vector<PairNodeHost>* pairs = &tri_pairs;
     if (merge) {
         int root = 0, height = 0;
-        if (pt::build_sah_pairs(own_boxes, MAX_SEARCH_HEIGHT, &merged_pairs, &root, &height) != PT_OK) {
+        if (pt::build_sah_pairs(own_boxes, search_height_cap(), &merged_pairs, &root, &height) != PT_OK) {
             pt::clear_error();
             return PT_OK;
         }

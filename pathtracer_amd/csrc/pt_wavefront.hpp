@@ -31,7 +31,7 @@ namespace ptd {
 #endif
 constexpr int SAMPLES_PER_CHUNK = PT_SAMPLES_PER_CHUNK;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
-constexpr int MAX_SEARCH_HEIGHT = 25;  // levels the rebuilt binary hierarchy is kept to
+constexpr int MAX_SEARCH_HEIGHT = 32;  // levels the rebuilt binary hierarchy is kept to (= STACK_DEPTH: a height cap near the minimum forces balanced splits and costs large scenes a third of their speed)
 constexpr int MAX_WF_STACK_SLOTS = 36; // per-lane stack slots a block is given at most (1 KB of LDS each): three blocks per CU still fit
 
 struct WorkParams {
