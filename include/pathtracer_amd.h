@@ -156,6 +156,24 @@ int pt_camera_look_at(const PtVec3* position, const PtVec3* target, double fov_y
 int pt_camera_frame(const PtCamera* camera, double aspect_ratio, int32_t width, int32_t height,
                     PtFrame* frame);
 
+/* One frame's worth of the reference's mouse and keyboard state (MouseInput / KeyboardInput as the frame loop
+ * reads them, src/main.cpp:892-985) and the seconds since the previous frame (:887). */
+typedef struct PtViewerInput {
+    int32_t left_button_held;            /* left button down in this frame and in the previous one (:895) */
+    int32_t mouse_delta_x, mouse_delta_y;/* pointer movement since the previous frame (:896-897)          */
+    int32_t scroll;                      /* wheel notches since the previous frame, either sign (:911-924) */
+    int32_t key_a, key_d, key_w, key_s;  /* move the target left/right/up/down (:934-952)                  */
+    int32_t key_q, key_e;                /* narrow / widen the field of view (:955-963)                    */
+    int32_t key_up, key_down;            /* focus distance (:966-974)                                      */
+    int32_t key_left, key_right;         /* aperture (:977-985)                                            */
+    double frame_duration;
+} PtViewerInput;
+/* The camera controls of the reference's frame loop (src/main.cpp:890-985): orbit by mouse drag (yaw about z,
+ * pitch about x, 4 degrees per pixel and second), zoom by wheel (distance * or / 0.95f per notch), target moved
+ * along the camera's x / y axes, field of view, focus distance and aperture by keys.  *camera_modified is set to
+ * 1 if anything changed (the reference then restarts its accumulation, :996-999), else 0. */
+int pt_camera_apply_input(PtCamera* camera, const PtViewerInput* input, int32_t* camera_modified);
+
 /* Built-in scenes.  PT_SCENE_MODEL is the reference's active scene
  * (src/main.cpp:800-840) with the model file chosen by the caller; the chess
  * scenes are this library's own definitions over the reference's six model
@@ -207,6 +225,16 @@ int pt_render(PtScene* scene, const PtFrame* frame, double* accum);
  * A launch on a different stream while the handle's previous launch is still running returns
  * PT_ERR_UNSUPPORTED and renders nothing; overlapping frames need one handle each. */
 int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
+
+/* One iteration of the reference's frame loop without the window (src/main.cpp:890-1036): the controls in
+ * `input` (may be null: nothing pressed) are applied to *camera; if that changed it, `accum_device` (4*width*height
+ * doubles in the HBM of the scene's device) is zeroed and *sample set to 0 (:996-999); every pixel's samples
+ * *sample .. *sample + samples_per_frame - 1 are added (the reference adds one per frame, :1001-1022; more per call
+ * give the bytes of as many frames with an unmoved camera); *sample is advanced (:1036).  pt_tonemap_device with
+ * sample_count = *sample then gives the frame the reference would show (:1024-1034).  Work is enqueued on
+ * `hip_stream`; the call returns after the launch. */
+int pt_viewer_frame(PtScene* scene, PtCamera* camera, const PtViewerInput* input, double aspect_ratio, int32_t width, int32_t height,
+                    int32_t samples_per_frame, int32_t* sample, double* accum_device, void* hip_stream);
 
 /* pt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same

@@ -108,6 +108,7 @@ class _CpuLib:
         self._call("rotation_matrix").argtypes = [C.c_double] * 4 + [C.c_void_p]
         self._call("camera_look_at").argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         self._call("camera_frame").argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p]
+        self._call("camera_apply_input").argtypes = [C.c_void_p, C.c_void_p]
         self._call("tonemap_bgra8").argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
         self._call("construct_triangle_bvh").argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         self._call("construct_sphere_bvh").argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -195,6 +196,10 @@ class _CpuLib:
         frame = PtFrame()
         self._call("camera_frame")(C.byref(camera), float(aspect_ratio), int(width), int(height), C.byref(frame))
         return frame
+
+    def camera_apply_input(self, camera, viewer_input):
+        """The frame loop's camera controls (src/main.cpp:890-985) applied to `camera` in place; True if it changed."""
+        return bool(self._call("camera_apply_input")(C.byref(camera), C.byref(viewer_input)))
 
     def primary_rays(self, frame, sample):
         rays = np.zeros((frame.height, frame.width, 6))

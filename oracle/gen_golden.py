@@ -211,6 +211,25 @@ def main():
     g["pawn640_accum16_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(accum).tobytes()).digest(), np.uint8)
     g["pawn640_accum16_sum"] = np.array([accum.reshape(-1, 4)[:, c].sum() for c in range(4)])
 
+    # ---- the frame loop's camera controls (src/main.cpp:890-985): 300 frames of seeded mouse / wheel / key input applied
+    # to the model scene's camera one after another; the camera (16 doubles) and camera_modified after every frame
+    from pathtracer_amd.ctypes_abi import PtViewerInput
+    rng = np.random.default_rng(77)
+    _, cam, _ = ref.model_scene(os.path.join(MODELS, "rook.triangles"))
+    inputs = np.zeros((300, 14), np.int32)
+    durations = rng.uniform(0.002, 0.04, 300)
+    inputs[:, 0] = rng.integers(0, 2, 300)
+    inputs[:, 1:3] = rng.integers(-25, 26, (300, 2))
+    inputs[:, 3] = np.where(rng.random(300) < 0.25, rng.integers(-3, 4, 300), 0)
+    inputs[:, 4:] = rng.random((300, 10)) < 0.12
+    inputs[0] = 0                                        # a frame with nothing pressed leaves the camera alone
+    cameras, modified = np.zeros((300, 16)), np.zeros(300, np.int32)
+    for i in range(300):
+        v = PtViewerInput(*[int(x) for x in inputs[i]], float(durations[i]))
+        modified[i] = ref.camera_apply_input(cam, v)
+        cameras[i] = np.frombuffer(bytes(cam), np.float64)
+    g["viewer_inputs"], g["viewer_durations"], g["viewer_cameras"], g["viewer_modified"] = inputs, durations, cameras, modified
+
     # ---- the head of one of the reference's ASCII-STL assets (data): its first 60 facets; the expected
     # triangles are the first 60 records of the matching .triangles asset
     stl = open("/root/reference/models/stl/rook.stl", "rb").read()

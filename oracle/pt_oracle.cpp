@@ -950,4 +950,52 @@ int orc_tonemap_bgra8(const double* accum, long long pixel_count, int sample_cou
     return 0;
 }
 
+// The camera controls of the frame loop, src/main.cpp:890-985 (PtViewerInput holds what MouseInput / KeyboardInput and
+// frame_duration hold there).  Returns 1 if the camera changed (camera_modified).
+int orc_camera_apply_input(PtCamera* cam, const PtViewerInput* in) {
+    int modified = 0;
+    const double dt = in->frame_duration;
+    if (in->left_button_held && (in->mouse_delta_x != 0 || in->mouse_delta_y != 0)) {              // :898-908
+        const double mouse_sensitivity = 4.0f;
+        const double yaw_delta = (double)in->mouse_delta_x * mouse_sensitivity * dt;
+        const double pitch_delta = -(double)in->mouse_delta_y * mouse_sensitivity * dt;
+        PtMat3 yaw, pitch, left, both;
+        orc_rotation_matrix(orc_degrees_to_radians(yaw_delta), 0.0f, 0.0f, 1.0f, &yaw);
+        orc_rotation_matrix(orc_degrees_to_radians(pitch_delta), 1.0f, 0.0f, 0.0f, &pitch);
+        mat_mul(yaw, cam->orientation, &left);
+        mat_mul(left, pitch, &both);
+        cam->orientation = both;
+        modified = 1;
+    }
+    const float scroll_sensitivity = 0.95f;                                                        // :910-924
+    if (in->scroll > 0) {
+        for (int i = 0; i < in->scroll; ++i) cam->distance *= scroll_sensitivity;
+        modified = 1;
+    } else if (in->scroll < 0) {
+        for (int i = in->scroll; i < 0; ++i) cam->distance /= scroll_sensitivity;
+        modified = 1;
+    }
+    const double (*m)[3] = cam->orientation.rows;                                                  // :928-929
+    const V3 cx{m[0][0], m[1][0], m[2][0]}, cy{m[0][1], m[1][1], m[2][1]};
+    const float camera_speed = 0.6f;                                                               // :932-952
+    auto move = [&](double sign, const V3& axis) {
+        const V3 step = scale(cam->distance * camera_speed * dt, axis);
+        const V3 t = (sign < 0.0) ? sub(v3(cam->target), step) : add(v3(cam->target), step);
+        cam->target = PtVec3{t.x, t.y, t.z};
+        modified = 1;
+    };
+    if (in->key_a) move(-1.0, cx);
+    if (in->key_d) move(+1.0, cx);
+    if (in->key_w) move(+1.0, cy);
+    if (in->key_s) move(-1.0, cy);
+    const double fov_sensitivity = 0.1f, focus_sensitivity = 1.0f, aperture_sensitivity = 0.1f;    // :954-985
+    if (in->key_q) { cam->fov_y -= fov_sensitivity * dt; modified = 1; }
+    if (in->key_e) { cam->fov_y += fov_sensitivity * dt; modified = 1; }
+    if (in->key_up) { cam->focus_distance += focus_sensitivity * dt * cam->distance; modified = 1; }
+    if (in->key_down) { cam->focus_distance -= focus_sensitivity * dt * cam->distance; modified = 1; }
+    if (in->key_left) { cam->aperture -= aperture_sensitivity * dt; modified = 1; }
+    if (in->key_right) { cam->aperture += aperture_sensitivity * dt; modified = 1; }
+    return modified;
+}
+
 }  // extern "C"

@@ -612,4 +612,50 @@ int ref_tonemap_bgra8(const double* accum, long long pixel_count, int sample_cou
 
 double ref_degrees_to_radians(double degrees) { return degrees_to_radians(degrees); }
 
+// The camera controls of the frame loop, src/main.cpp:890-985, with the reference's own matrix and vector code; the
+// Win32 input structs (MouseInput / KeyboardInput, src/main.cpp:214-260) are replaced by PtViewerInput.  Returns camera_modified.
+int ref_camera_apply_input(PtCamera* cam, const PtViewerInput* in) {
+    Camera camera;
+    std::memcpy(&camera, cam, sizeof(camera));
+    const real frame_duration = in->frame_duration;
+    bool camera_modified = false;
+    const bool left_mouse_button_held = in->left_button_held != 0;
+    const int mouse_delta_x = in->mouse_delta_x, mouse_delta_y = in->mouse_delta_y;
+    if (left_mouse_button_held && (mouse_delta_x != 0 || mouse_delta_y != 0)) {                     // :898-908
+        static constexpr real MOUSE_SENSITIVITY = 4.0f;
+        const real camera_yaw_delta = static_cast<real>(mouse_delta_x) * MOUSE_SENSITIVITY * frame_duration;
+        const real camera_pitch_delta = -static_cast<real>(mouse_delta_y) * MOUSE_SENSITIVITY * frame_duration;
+        const Mat3 camera_yaw_delta_rotation = rotation_matrix(degrees_to_radians(camera_yaw_delta), 0.0f, 0.0f, 1.0f);
+        const Mat3 camera_pitch_delta_rotation = rotation_matrix(degrees_to_radians(camera_pitch_delta), 1.0f, 0.0f, 0.0f);
+        camera.orientation = camera_yaw_delta_rotation * camera.orientation * camera_pitch_delta_rotation;
+        camera_modified = true;
+    }
+    static constexpr float SCROLL_SENSITIVITY = 0.95f;                                              // :910-924
+    if (in->scroll > 0) {
+        for (int i = 0; i < in->scroll; ++i) camera.distance *= SCROLL_SENSITIVITY;
+        camera_modified = true;
+    } else if (in->scroll < 0) {
+        for (int i = in->scroll; i < 0; ++i) camera.distance /= SCROLL_SENSITIVITY;
+        camera_modified = true;
+    }
+    const Vec3 camera_x = get_column(camera.orientation, 0);                                        // :928-929
+    const Vec3 camera_y = get_column(camera.orientation, 1);
+    static constexpr float CAMERA_SPEED = 0.6f;                                                     // :932-952
+    if (in->key_a) { camera.target = camera.target - camera.distance * CAMERA_SPEED * frame_duration * camera_x; camera_modified = true; }
+    if (in->key_d) { camera.target = camera.target + camera.distance * CAMERA_SPEED * frame_duration * camera_x; camera_modified = true; }
+    if (in->key_w) { camera.target = camera.target + camera.distance * CAMERA_SPEED * frame_duration * camera_y; camera_modified = true; }
+    if (in->key_s) { camera.target = camera.target - camera.distance * CAMERA_SPEED * frame_duration * camera_y; camera_modified = true; }
+    static constexpr real FOV_SENSITIVITY = 0.1f;                                                   // :954-963
+    if (in->key_q) { camera.fov_y -= FOV_SENSITIVITY * frame_duration; camera_modified = true; }
+    if (in->key_e) { camera.fov_y += FOV_SENSITIVITY * frame_duration; camera_modified = true; }
+    static constexpr real FOCUS_SENSITIVITY = 1.0f;                                                 // :965-974
+    if (in->key_up) { camera.focus_distance += FOCUS_SENSITIVITY * frame_duration * camera.distance; camera_modified = true; }
+    if (in->key_down) { camera.focus_distance -= FOCUS_SENSITIVITY * frame_duration * camera.distance; camera_modified = true; }
+    static constexpr real APERTURE_SENSITIVITY = 0.1f;                                              // :976-985
+    if (in->key_left) { camera.aperture -= APERTURE_SENSITIVITY * frame_duration; camera_modified = true; }
+    if (in->key_right) { camera.aperture += APERTURE_SENSITIVITY * frame_duration; camera_modified = true; }
+    std::memcpy(cam, &camera, sizeof(camera));
+    return camera_modified ? 1 : 0;
+}
+
 }  // extern "C"

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from . import ctypes_abi as abi
-from .ctypes_abi import (MATERIAL_DTYPE, NODE_DTYPE, PtCamera, PtFrame, PtMat3, PtSceneDesc, PtVec3, ptr)
+from .ctypes_abi import (MATERIAL_DTYPE, NODE_DTYPE, PtCamera, PtFrame, PtMat3, PtSceneDesc, PtVec3, PtViewerInput, ptr)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
@@ -17,7 +17,7 @@ MODELS_DIR = os.path.join(os.path.dirname(_HERE), "assets", "models")
 
 EXPORTS = [
     "pt_last_error", "pt_load_triangles_file", "pt_save_triangles_file", "pt_parse_stl_file", "pt_free", "pt_construct_triangle_bvh",
-    "pt_construct_sphere_bvh", "pt_rotation_matrix", "pt_look_at_matrix", "pt_camera_look_at", "pt_camera_frame",
+    "pt_construct_sphere_bvh", "pt_rotation_matrix", "pt_look_at_matrix", "pt_camera_look_at", "pt_camera_frame", "pt_camera_apply_input", "pt_viewer_frame",
     "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8", "pt_tonemap_device",
     "pt_write_pixel_data_file", "pt_write_ppm_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_device_noalloc", "pt_primary_hits", "pt_last_render_ms", "pt_last_render_stats", "pt_device_eval",
@@ -64,6 +64,9 @@ def lib():
         dll.pt_look_at_matrix.argtypes = [C.c_void_p] * 3
         dll.pt_camera_look_at.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         dll.pt_camera_frame.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_void_p]
+        dll.pt_camera_apply_input.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        dll.pt_viewer_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                        C.c_void_p, C.c_void_p]
         dll.pt_host_scene_build.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
         dll.pt_host_scene_desc.argtypes = [C.c_void_p, C.c_void_p]
         dll.pt_host_scene_camera.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -150,6 +153,13 @@ def camera_frame(camera, aspect_ratio, width, height, **changes):
     for key, value in changes.items():
         setattr(frame, key, value)
     return frame
+
+
+def camera_apply_input(camera, viewer_input):
+    """pt_camera_apply_input: updates `camera` in place; returns True if it changed."""
+    modified = C.c_int32()
+    check(lib().pt_camera_apply_input(C.byref(camera), C.byref(viewer_input), C.byref(modified)))
+    return bool(modified.value)
 
 
 def tonemap_bgra8(accum, sample_count):
@@ -253,6 +263,14 @@ class DeviceScene:
         """pt_render_device: accum_device_ptr is a raw HBM address; returns after the launch."""
         check(lib().pt_render_device(self.handle, C.byref(frame), C.c_void_p(accum_device_ptr),
                                      C.c_void_p(stream) if stream else None))
+
+    def viewer_frame(self, camera, viewer_input, aspect_ratio, width, height, sample, accum_device_ptr, samples_per_frame=1, stream=None):
+        """pt_viewer_frame: one iteration of the reference's frame loop; returns the advanced sample counter."""
+        counter = C.c_int32(int(sample))
+        check(lib().pt_viewer_frame(self.handle, C.byref(camera), None if viewer_input is None else C.byref(viewer_input), float(aspect_ratio),
+                                    int(width), int(height), int(samples_per_frame), C.byref(counter), C.c_void_p(accum_device_ptr),
+                                    C.c_void_p(stream) if stream else None))
+        return counter.value
 
     def render_device_noalloc(self, frame, accum_device_ptr, stream=None):
         """pt_render_device_noalloc: same as render_device, without any device allocation (bounded frame size)."""

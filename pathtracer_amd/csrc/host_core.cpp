@@ -297,6 +297,42 @@ int pt_camera_frame(const PtCamera* camera, double aspect_ratio, int32_t width, 
     return PT_OK;
 }
 
+int pt_camera_apply_input(PtCamera* camera, const PtViewerInput* in, int32_t* camera_modified) {
+    if (camera == nullptr || in == nullptr || camera_modified == nullptr) return fail(PT_ERR_INVALID_ARGUMENT, "pt_camera_apply_input: null argument");
+    bool modified = false;
+    const double dt = in->frame_duration;
+    if (in->left_button_held != 0 && (in->mouse_delta_x != 0 || in->mouse_delta_y != 0)) {            // src/main.cpp:898-908
+        const double sensitivity = 4.0f;
+        const double yaw = static_cast<double>(in->mouse_delta_x) * sensitivity * dt;
+        const double pitch = -static_cast<double>(in->mouse_delta_y) * sensitivity * dt;
+        const PtMat3 yaw_rotation = rotation(degrees_to_radians(yaw), 0.0f, 0.0f, 1.0f);
+        const PtMat3 pitch_rotation = rotation(degrees_to_radians(pitch), 1.0f, 0.0f, 0.0f);
+        camera->orientation = multiply(multiply(yaw_rotation, camera->orientation), pitch_rotation);
+        modified = true;
+    }
+    const float scroll_sensitivity = 0.95f;                                                           // :910-924
+    for (int i = 0; i < in->scroll; ++i) camera->distance *= scroll_sensitivity;
+    for (int i = in->scroll; i < 0; ++i) camera->distance /= scroll_sensitivity;
+    modified = modified || in->scroll != 0;
+    const PtMat3& o = camera->orientation;                                                            // :928-929, after the drag
+    const PtVec3 camera_x{o.rows[0][0], o.rows[1][0], o.rows[2][0]};
+    const PtVec3 camera_y{o.rows[0][1], o.rows[1][1], o.rows[2][1]};
+    const float camera_speed = 0.6f;                                                                  // :932-952
+    if (in->key_a != 0) { camera->target = camera->target - (camera->distance * camera_speed * dt) * camera_x; modified = true; }
+    if (in->key_d != 0) { camera->target = camera->target + (camera->distance * camera_speed * dt) * camera_x; modified = true; }
+    if (in->key_w != 0) { camera->target = camera->target + (camera->distance * camera_speed * dt) * camera_y; modified = true; }
+    if (in->key_s != 0) { camera->target = camera->target - (camera->distance * camera_speed * dt) * camera_y; modified = true; }
+    const double fov_sensitivity = 0.1f, focus_sensitivity = 1.0f, aperture_sensitivity = 0.1f;       // :954-985
+    if (in->key_q != 0) { camera->fov_y -= fov_sensitivity * dt; modified = true; }
+    if (in->key_e != 0) { camera->fov_y += fov_sensitivity * dt; modified = true; }
+    if (in->key_up != 0) { camera->focus_distance += focus_sensitivity * dt * camera->distance; modified = true; }
+    if (in->key_down != 0) { camera->focus_distance -= focus_sensitivity * dt * camera->distance; modified = true; }
+    if (in->key_left != 0) { camera->aperture -= aperture_sensitivity * dt; modified = true; }
+    if (in->key_right != 0) { camera->aperture += aperture_sensitivity * dt; modified = true; }
+    *camera_modified = modified ? 1 : 0;
+    return PT_OK;
+}
+
 int pt_tonemap_bgra8(const double* accum, int64_t pixel_count, int32_t sample_count, uint8_t* out) {
     if (accum == nullptr || out == nullptr || pixel_count < 0 || sample_count <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_tonemap_bgra8: bad argument");
     const double samples = static_cast<double>(sample_count);

@@ -869,6 +869,34 @@ int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device,
     return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream), Workspace{});
 }
 
+int pt_viewer_frame(PtScene* scene, PtCamera* camera, const PtViewerInput* input, double aspect_ratio, int32_t width, int32_t height,
+                    int32_t samples_per_frame, int32_t* sample, double* accum_device, void* hip_stream) {
+    if (scene == nullptr || camera == nullptr || sample == nullptr || accum_device == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_viewer_frame: null argument");
+    if (samples_per_frame < 1 || *sample < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_viewer_frame: samples_per_frame must be positive and *sample non-negative");
+    int32_t modified = 0;
+    if (input != nullptr) {
+        const int rc = pt_camera_apply_input(camera, input, &modified);
+        if (rc != PT_OK) return rc;
+    }
+    PtFrame frame;
+    int rc = pt_camera_frame(camera, aspect_ratio, width, height, &frame);                     // src/main.cpp:987-994
+    if (rc != PT_OK) return rc;
+    rc = check_frame(&frame);
+    if (rc != PT_OK) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(scene->device));
+    if (modified != 0) {                                                                       // :996-999
+        HIP_TRY(hipMemsetAsync(accum_device, 0, 4ull * width * height * sizeof(double), stream));
+        *sample = 0;
+    }
+    frame.sample_begin = *sample;
+    frame.sample_count = samples_per_frame;
+    rc = launch_render(scene, &frame, accum_device, stream, Workspace{});                      // :1001-1022
+    if (rc != PT_OK) return rc;
+    *sample += samples_per_frame;                                                              // :1036
+    return PT_OK;
+}
+
 int pt_render_device_noalloc(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream) {
     if (scene == nullptr || accum_device == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_render_device_noalloc: null argument");
     const int rc = check_frame(frame);

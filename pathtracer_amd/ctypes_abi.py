@@ -54,6 +54,13 @@ class PtCamera(C.Structure):
                 ("aperture", C.c_double), ("focus_distance", C.c_double)]
 
 
+class PtViewerInput(C.Structure):
+    _fields_ = [("left_button_held", C.c_int32), ("mouse_delta_x", C.c_int32), ("mouse_delta_y", C.c_int32), ("scroll", C.c_int32),
+                ("key_a", C.c_int32), ("key_d", C.c_int32), ("key_w", C.c_int32), ("key_s", C.c_int32),
+                ("key_q", C.c_int32), ("key_e", C.c_int32), ("key_up", C.c_int32), ("key_down", C.c_int32),
+                ("key_left", C.c_int32), ("key_right", C.c_int32), ("frame_duration", C.c_double)]
+
+
 class PtSceneDesc(C.Structure):
     _fields_ = [
         ("materials", C.c_void_p), ("material_count", C.c_int32),
@@ -97,7 +104,7 @@ MATERIAL_DTYPE = np.dtype([("v", np.float64, (4,)), ("type", np.int32), ("pad_",
 assert C.sizeof(PtVec3) == 24 and C.sizeof(PtMat3) == 72 and C.sizeof(PtCamera) == 128
 assert NODE_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 40
 assert C.sizeof(PtFrame) == 8 * 4 + 8 + 6 * 24 + 8
-assert C.sizeof(PtSceneDesc) == 144
+assert C.sizeof(PtSceneDesc) == 144 and C.sizeof(PtViewerInput) == 64
 
 
 def ptr(array):

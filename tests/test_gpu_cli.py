@@ -108,3 +108,38 @@ def test_bench_script_with_two_ranks_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["verified"] is True
     assert line["value"] > 0 and line["unit"] == "Msamples/s" and line["scaling"] == "strong"
     assert line["roofline"]["paths_per_launch"] == 640 * 360 * 16 / 2
+
+
+def test_viewer_frames_accumulate_and_restart_like_the_reference_loop(api, orc):
+    """pt_viewer_frame = one iteration of the reference's frame loop (src/main.cpp:890-1036): frames with an unmoved
+    camera add one sample each; a frame whose input moves the camera zeroes the buffer and starts again at sample 0;
+    several samples per call give the bytes of as many frames."""
+    import torch
+    host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, "rook.triangles"))
+    device = api.DeviceScene.from_host(host)
+    checker = orc.scene_create(host.arrays())
+    w, h = 120, 96
+    camera = abi.PtCamera.from_buffer_copy(bytes(host.camera))
+    accum = torch.full((h, w, 4), 7.0, dtype=torch.float64, device="cuda:0")      # stale contents: the first frame must not clear them ...
+    accum.zero_()                                                                 # ... the caller does, as the reference allocates zeroed memory
+    sample = 0
+    for _ in range(3):
+        sample = device.viewer_frame(camera, None, host.aspect_ratio, w, h, sample, accum.data_ptr())
+    torch.cuda.synchronize()
+    assert sample == 3
+    assert same_bits(accum.cpu().numpy().ravel(), checker.render(host.frame(w, h, sample_count=3), threads=8))
+    # the mouse is dragged and the wheel turned: new camera, accumulation restarts
+    drag = abi.PtViewerInput(1, 14, -9, 2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0.016)
+    sample = device.viewer_frame(camera, drag, host.aspect_ratio, w, h, sample, accum.data_ptr())
+    idle = abi.PtViewerInput(0, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.016)     # pointer moves without the button: nothing changes
+    sample = device.viewer_frame(camera, idle, host.aspect_ratio, w, h, sample, accum.data_ptr(), samples_per_frame=4)
+    torch.cuda.synchronize()
+    assert sample == 5
+    moved = abi.PtCamera.from_buffer_copy(bytes(host.camera))
+    assert orc.camera_apply_input(moved, drag) and bytes(moved) == bytes(camera) != bytes(host.camera)
+    frame = api.camera_frame(moved, host.aspect_ratio, w, h, sample_count=5)
+    assert same_bits(accum.cpu().numpy().ravel(), checker.render(frame, threads=8))
+    image = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    api.tonemap_device(0, accum.data_ptr(), w * h, sample, image.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(image.cpu().numpy().ravel(), orc.tonemap_bgra8(checker.render(frame, threads=8), 5))

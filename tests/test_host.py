@@ -211,3 +211,19 @@ def test_scene_create_rejects_bad_input_without_a_gpu(api):
     code, message = create(materials=mats)
     assert code == abi.PT_ERR_INVALID_ARGUMENT and "unknown type" in message
     assert api.lib().pt_scene_create(None, 0, C.byref(handle)) == abi.PT_ERR_INVALID_ARGUMENT
+
+
+def test_viewer_camera_controls_follow_the_reference(api, orc, golden):
+    """pt_camera_apply_input (src/main.cpp:890-985) over 300 frames of mouse, wheel and key input applied one after
+    another: the camera after every frame, and whether it changed, as the reference's own code left them; the CPU
+    restatement agrees too."""
+    host = api.HostScene(abi.PT_SCENE_MODEL, os.path.join(MODELS, "rook.triangles"))
+    mine, theirs = abi.PtCamera.from_buffer_copy(bytes(host.camera)), abi.PtCamera.from_buffer_copy(bytes(host.camera))
+    for i in range(len(golden["viewer_inputs"])):
+        v = abi.PtViewerInput(*[int(x) for x in golden["viewer_inputs"][i]], float(golden["viewer_durations"][i]))
+        assert api.camera_apply_input(mine, v) == bool(golden["viewer_modified"][i])
+        assert orc.camera_apply_input(theirs, v) == bool(golden["viewer_modified"][i])
+        assert bytes(mine) == golden["viewer_cameras"][i].tobytes() == bytes(theirs), i
+    assert not golden["viewer_modified"][0] and golden["viewer_modified"].sum() > 200
+    with pytest.raises(api.PathTracerError):
+        api.check(api.lib().pt_camera_apply_input(None, None, None))
