@@ -50,10 +50,20 @@ PATH_STORE_BYTES = 32           # one colour record per path
 
 
 def table(name, key):
+    """The committed counter entry of workload `key` ("scene WxH Nspp depthD"), or, if that size was not profiled, the
+    scene's entry at another size with the same bounce limit: per-path figures barely depend on resolution and sample
+    count.  Returns (entry, paths of the profiled launch, key used)."""
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None
-    return json.load(open(path)).get(key)
+        return None, None, None
+    entries = json.load(open(path))
+    scene, _, _, depth = key.split()
+    used = key if key in entries else next((k for k in sorted(entries) if k.split()[0] == scene and k.split()[3] == depth), None)
+    if used is None:
+        return None, None, None
+    _, size, spp, _ = used.split()
+    width, height = (int(v) for v in size.split("x"))
+    return entries[used], width * height * int(spp[:-3]), used
 
 
 def algorithmic_work(scene, width, height, max_bounces):
@@ -233,9 +243,9 @@ def main():
         compute_units = torch.cuda.get_device_properties(device).multi_processor_count
         valu_peak = compute_units * SIMDS_PER_CU * LANES_PER_SIMD * CLOCK_GHZ * 1e9 / 1e12      # T lane-operations / s
 
-        per_path = table("executed_work.json", workload)             # committed rocprofv3 instruction counts of this workload
-        traffic = table("hbm_traffic.json", workload)
-        hbm_bytes = None if traffic is None else traffic["trace_paths_kernel"]["hbm_bytes_per_launch"] / world
+        per_path, _, work_from = table("executed_work.json", workload)      # committed rocprofv3 instruction counts of this workload
+        traffic, traffic_paths, traffic_from = table("hbm_traffic.json", workload)
+        hbm_bytes = None if traffic is None else traffic["trace_paths_kernel"]["hbm_bytes_per_launch"] / traffic_paths * launch_paths
         valu = hbm = None
         if per_path is not None:
             tops = per_path["valu_wave_instructions_per_path"] * 64 * launch_paths / launch_s / 1e12
@@ -253,7 +263,8 @@ def main():
         if candidates:
             roofline = dict(max(candidates, key=lambda r: r["frac"]))
         roofline.update({"traffic": hbm_bytes, "kernel": "trace_paths_kernel (+ sum_samples_kernel, 2% of the time)", "kernel_ms": launch_s * 1e3,
-                         "paths_per_launch": launch_paths, "valu": valu, "hbm": hbm})
+                         "paths_per_launch": launch_paths, "valu": valu, "hbm": hbm,
+                         "counters_profiled_on": {"valu": work_from, "hbm": traffic_from}})
 
         work, work_key = algorithmic_work(scene_name, w, h, args.max_bounces)
         executed = executed_steps(scene, host, w, h, args.stats_spp, args.max_bounces, device) if (world == 1 and args.stats_spp > 0) else None
