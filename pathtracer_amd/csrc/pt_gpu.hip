@@ -544,7 +544,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void tonemap_kernel(const double* __
 struct Tunables {
     bool force_pixels_kernel = false;   // PT_KERNEL=pixels: always the one-lane-per-pixel kernel
     int stats = 0;                      // PT_STATS=1: phase/lane counters + box-test cross-check; 2: counters + per-section clocks
-    double workspace_gb = 24.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer
+    double workspace_gb = 96.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer (a third of the 288 GB; also bounded by what is free)
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild

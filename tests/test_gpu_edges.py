@@ -137,3 +137,31 @@ def test_two_spheres_and_two_triangles(api, orc):
     tri, sph = _compare(api, orc, _scene(api, triangles, spheres, tri_materials=[0, 3], sph_materials=[1, 2]), (0.0, 2.0, 9.0), (0.0, 0.0, 0.0),
                         size=(48, 36), spp=4, bounces=16)
     assert (tri >= 0).any() and (sph == 0).any() and (sph == 1).any()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scenes_against_the_checker(api, orc, seed):
+    """Seeded random scenes of every shape the library takes: triangle soups of 1..400 triangles (some on an integer
+    lattice, so that coplanar and duplicated triangles tie), 0..40 spheres (hollow ones in every fourth scene), all
+    four materials, cameras inside and outside the geometry, odd image sizes.  Primary hit indices and buffers, bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    count = int(rng.choice([1, 2, 7, 33, 150, 400]))
+    if seed % 3 == 0:
+        base = rng.integers(-6, 7, (count, 1, 3)).astype(float)
+        triangles = (base + rng.integers(0, 3, (count, 3, 3))).reshape(-1, 9)          # lattice: exact ties and degenerate triangles
+        triangles = np.concatenate([triangles, triangles[: max(1, count // 5)]])            # and exact duplicates
+    else:
+        centre = rng.uniform(-8, 8, (count, 1, 3))
+        triangles = (centre + rng.normal(0, rng.uniform(0.2, 3.0), (count, 3, 3))).reshape(-1, 9)
+    spheres = None
+    if seed % 2 == 1:
+        n = int(rng.choice([1, 2, 5, 40]))
+        spheres = np.concatenate([rng.uniform(-8, 8, (n, 3)), rng.uniform(0.3, 2.5, (n, 1))], 1)
+        if seed % 4 == 3:
+            spheres[::2, 3] *= -1.0                                                    # hollow: inverted boxes
+    arrays = _scene(api, triangles, spheres, tri_materials=rng.integers(0, 4, len(triangles)),
+                    sph_materials=None if spheres is None else rng.integers(0, 4, len(spheres)))
+    eye = tuple(rng.uniform(-4, 4, 3)) if seed % 5 == 0 else tuple(rng.uniform(12, 25, 3) * rng.choice([-1, 1], 3))
+    size = (int(rng.integers(9, 70)), int(rng.integers(9, 50)))
+    _compare(api, orc, arrays, eye, (0.0, 0.0, 0.0), size=size, spp=int(rng.integers(1, 4)), bounces=int(rng.choice([1, 4, 12, 50])),
+             aperture=float(rng.choice([0.0, 0.05, 0.6])))
