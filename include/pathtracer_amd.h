@@ -138,7 +138,9 @@ void pt_free(void* p);
 
 /* construct_triangle_bvh / construct_sphere_bvh (src/bvh.cpp:81-100 / :60-79).
  * `nodes` must hold 2*count-1 records; the output is identical, node for node,
- * to the reference's std::vector<Node>. */
+ * to the reference's std::vector<Node> when both are built with the same standard library:
+ * the reference sorts with std::sort, which is unstable, so which of several primitives with
+ * equal box minima goes left at a split is the library's choice (libstdc++ here). */
 int pt_construct_triangle_bvh(const PtTriangle* triangles, int32_t count, PtBvhNode* nodes);
 int pt_construct_sphere_bvh(const PtSphere* spheres, int32_t count, PtBvhNode* nodes);
 
@@ -263,8 +265,8 @@ int pt_tonemap_device(int32_t device, const double* accum_device, int64_t pixel_
 int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_index, int32_t* sphere_index);
 
 /* Kernel time in milliseconds of the most recent pt_render / pt_render_device on
- * this scene, measured with HIP events on the launch stream (blocks until the
- * launch has finished).  Not in the reference: measurement only. */
+ * this scene (pt_viewer_frame and pt_primary_hits launch too and count), measured with HIP events
+ * on the launch stream (blocks until the launch has finished).  Not in the reference: measurement only. */
 int pt_last_render_ms(PtScene* scene, float* ms);
 
 /* Profiling aid, not in the reference: with PT_STATS=1 in the environment the wavefront kernel

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of profiles/r2_profile.sh (gpurun_out/r2/<name>/) into the tables bench.py reads:
+"""Turns the rocprofv3 outputs of profiles/profile_workload.sh (gpurun_out/r2/<name>/) into the tables bench.py reads:
 profiles/executed_work.json, profiles/hbm_traffic.json, and a summary per workload under profiles/r2/<name>/.
-usage: python profiles/r2_tables.py name:scene:WxH:spp:bounces ..."""
+usage: python profiles/make_tables.py name:scene:WxH:spp:bounces ..."""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 profiles of the final build, one workload per call:
-#   profiles/r2_profile.sh <name> <scene> <WxH> <spp> <bounces>
+# Kernel trace and counter passes of one workload per call:
+#   profiles/profile_workload.sh <name> <scene> <WxH> <spp> <bounces>
 # kernel trace + stats, then counter passes (each its own rocprofv3 run), all under gpurun_out/r2/<name>/.
 export TMPDIR=/tmp
 name=$1; scene=$2; size=$3; spp=$4; bounces=$5
