@@ -18,8 +18,9 @@ HOST_OBJS := $(HOST_SRCS:.cpp=.o)
 HIP_OBJS  := $(CSRC)/pt_gpu.o
 
 CONSUMER := tests/consumer/render_rook
+DIGEST   := tests/consumer/hierarchy_digest
 
-all: $(LIB) oracle $(CONSUMER)
+all: $(LIB) oracle $(CONSUMER) $(DIGEST)
 
 $(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/pt_internal.h $(CSRC)/pt_traverse_host.h include/pathtracer_amd.h
 	$(CXX) $(HOSTFLAGS) -c -o $@ $<
@@ -34,11 +35,16 @@ $(LIB): $(HOST_OBJS) $(HIP_OBJS)
 $(CONSUMER): tests/consumer/render_rook.c include/pathtracer_amd.h $(LIB)
 	gcc -std=c11 -O2 -ffp-contract=off -Wall -Wextra -Iinclude -o $@ $< -Lpathtracer_amd -lpathtracer_amd -Wl,-rpath,'$$ORIGIN/../../pathtracer_amd'
 
+# Digests of what the host-side builders make (reference-shaped BVH, search hierarchy, four-wide nodes): the CPU tests
+# run it with different thread counts.
+$(DIGEST): tests/consumer/hierarchy_digest.cpp $(HOST_OBJS)
+	$(CXX) $(HOSTFLAGS) -Iinclude -o $@ $< $(HOST_OBJS)
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -f $(HOST_OBJS) $(HIP_OBJS) $(LIB) $(CONSUMER)
+	rm -f $(HOST_OBJS) $(HIP_OBJS) $(LIB) $(CONSUMER) $(DIGEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

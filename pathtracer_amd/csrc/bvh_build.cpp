@@ -12,6 +12,7 @@
 // range nobody reads again and is not reproduced.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -42,6 +43,76 @@ struct Job { int node, axis, begin, end; };
 
 struct KeyedIndex { double key; int index; };
 
+inline bool key_less(const KeyedIndex& l, const KeyedIndex& r) { return l.key < r.key; }
+
+// std::sort(first, last, key_less) by several threads, with the permutation std::sort itself leaves (equal keys
+// included).  libstdc++'s std::sort is an introsort: partition steps about a median-of-three pivot until a range is
+// 16 long or the depth budget (2 log2 n) is spent (then a heap sort of that range), and one insertion-sort pass over
+// everything at the end.  After a partition step the two sides never exchange elements again (left <= pivot <= right, and the
+// final pass moves an element left only past strictly greater ones), so the sides can go to different threads, each
+// finishing with the insertion pass over its own range.  The steps themselves are the library's own functions, called in
+// the library's own order per range; with another standard library this is a plain std::sort.
+class SortTeam {
+public:
+    static void sort(KeyedIndex* first, KeyedIndex* last, int threads) {
+#if defined(__GLIBCXX__)
+        if (threads > 1 && last - first > 2 * GRAIN) {
+            SortTeam team;
+            team.tasks.push_back(Task{first, last, static_cast<long>(std::__lg(last - first)) * 2});
+            std::vector<std::thread> others;
+            for (int t = 1; t < threads; ++t) others.emplace_back([&team]() { team.work(); });
+            team.work();
+            for (std::thread& t : others) t.join();
+            return;
+        }
+#endif
+        (void)threads;
+        std::sort(first, last, key_less);
+    }
+
+private:
+    static constexpr long GRAIN = 1 << 14;       // ranges up to this long are finished by the thread that has them
+    struct Task { KeyedIndex* first; KeyedIndex* last; long depth; };
+    std::mutex lock;
+    std::condition_variable changed;
+    std::vector<Task> tasks;
+    int running = 0;
+
+#if defined(__GLIBCXX__)
+    void work() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> hold(lock);
+                changed.wait(hold, [this]() { return !tasks.empty() || running == 0; });
+                if (tasks.empty()) return;            // nothing queued and nobody left who could queue more
+                t = tasks.back();
+                tasks.pop_back();
+                ++running;
+            }
+            auto less = __gnu_cxx::__ops::__iter_comp_iter(key_less);
+            while (t.last - t.first > GRAIN && t.depth > 0) {
+                --t.depth;
+                KeyedIndex* cut = std::__unguarded_partition_pivot(t.first, t.last, less);
+                {
+                    std::lock_guard<std::mutex> hold(lock);
+                    tasks.push_back(Task{cut, t.last, t.depth});
+                }
+                changed.notify_one();
+                t.last = cut;
+            }
+            std::__introsort_loop(t.first, t.last, t.depth, less);
+            std::__insertion_sort(t.first, t.last, less);
+            {
+                std::lock_guard<std::mutex> hold(lock);
+                --running;
+            }
+            changed.notify_all();
+        }
+    }
+#endif
+};
+
 struct Build {
     const std::vector<PtAabb>& boxes;
     std::vector<int>& order;
@@ -52,41 +123,28 @@ struct Build {
     // the indices first: the comparisons then read consecutive memory instead of boxes all over the array.  What
     // std::sort does depends only on the outcomes of the comparisons it makes, and those are the same, so the
     // permutation is the one the reference's call produces (equal keys included).
-    void sort_range(int axis, int begin, int end) const {
+    void sort_range(int axis, int begin, int end, int threads = 1) const {
         const PtAabb* b = boxes.data();
-        KeyedIndex* first = keyed.data() + begin;
-        KeyedIndex* last = keyed.data() + end;
-        const int* from = order.data() + begin;
-        for (KeyedIndex* k = first; k != last; ++k, ++from) {
-            const PtVec3& m = b[*from].min;
-            *k = KeyedIndex{axis == 0 ? m.x : (axis == 1 ? m.y : m.z), *from};
-        }
-        std::sort(first, last, [](const KeyedIndex& l, const KeyedIndex& r) { return l.key < r.key; });
-        int* to = order.data() + begin;
-        for (KeyedIndex* k = first; k != last; ++k, ++to) *to = k->index;
+        KeyedIndex* keys = keyed.data();
+        int* ids = order.data();
+        const int team = (end - begin >= (1 << 16)) ? threads : 1;
+        in_parts(begin, end, team, [=](long long from, long long to, int) {
+            for (long long i = from; i < to; ++i) {
+                const PtVec3& m = b[ids[i]].min;
+                keys[i] = KeyedIndex{axis == 0 ? m.x : (axis == 1 ? m.y : m.z), ids[i]};
+            }
+        });
+        SortTeam::sort(keys + begin, keys + end, team);
+        in_parts(begin, end, team, [=](long long from, long long to, int) {
+            for (long long i = from; i < to; ++i) ids[i] = keys[i].index;
+        });
     }
 
-    // Fills node `self` and its whole subtree; returns nothing, the box is read back from nodes[self].
-    // With `deferred` set, subtrees smaller than `defer_below` are queued instead of built, and the two
-    // halves of a node above them are handled by two threads down to `fork_levels` levels (each
-    // std::sort call still sees exactly the sequence the serial build would give it, so ties fall the
-    // same way).
-    void fill(int self, int axis, int begin, int end, std::vector<Job>* deferred, int defer_below, int fork_levels = 0,
-              std::mutex* deferred_lock = nullptr) const {
-        PtBvhNode& node = nodes[self];
+    // Fills node `self` and its whole subtree.
+    void fill(int self, int axis, int begin, int end) const {
         const int count = end - begin;
         if (count == 1) {
-            const int primitive = order[begin];
-            node.aabb = boxes[primitive];
-            node.index = primitive;
-            node.left = node.right = 0;
-            node.pad_ = 0;
-            return;
-        }
-        if (deferred != nullptr && count < defer_below) {
-            if (deferred_lock != nullptr) deferred_lock->lock();
-            deferred->push_back(Job{self, axis, begin, end});
-            if (deferred_lock != nullptr) deferred_lock->unlock();
+            set_leaf(self, order[begin]);
             return;
         }
         sort_range(axis, begin, end);
@@ -94,19 +152,26 @@ struct Build {
         const int mid = begin + count / 2;
         const int left = self + 1;
         const int right = self + 2 * (mid - begin);
-        if (deferred != nullptr && fork_levels > 0) {
-            std::thread other([&]() { fill(left, next_axis, begin, mid, deferred, defer_below, fork_levels - 1, deferred_lock); });
-            fill(right, next_axis, mid, end, deferred, defer_below, fork_levels - 1, deferred_lock);
-            other.join();
-        } else {
-            fill(left, next_axis, begin, mid, deferred, defer_below, 0, deferred_lock);
-            fill(right, next_axis, mid, end, deferred, defer_below, 0, deferred_lock);
-        }
+        fill(left, next_axis, begin, mid);
+        fill(right, next_axis, mid, end);
+        set_inner(self, left, right);
+        join(self);
+    }
+
+    void set_leaf(int self, int primitive) const {
+        PtBvhNode& node = nodes[self];
+        node.aabb = boxes[primitive];
+        node.index = primitive;
+        node.left = node.right = 0;
+        node.pad_ = 0;
+    }
+
+    void set_inner(int self, int left, int right) const {
+        PtBvhNode& node = nodes[self];
         node.index = 0;
         node.left = left;
         node.right = right;
         node.pad_ = 0;
-        if (deferred == nullptr) join(self);
     }
 
     void join(int self) const {            // operator+=, src/geometry.cpp:39-49
@@ -133,33 +198,48 @@ void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads) 
     const int count = static_cast<int>(boxes.size());
     if (count == 0) return;
     std::vector<int> order(count);
-    for (int i = 0; i < count; ++i) order[i] = i;
     std::vector<KeyedIndex> keyed(count);
     Build build{boxes, order, nodes, keyed};
     if (threads <= 1 || count < 1 << 15) {
-        build.fill(0, 0, 0, count, nullptr, 0);
+        for (int i = 0; i < count; ++i) order[i] = i;
+        build.fill(0, 0, 0, count);
         return;
     }
-    // The top of the tree down to subtrees of < count/(4*threads) primitives (its first levels forked
-    // over threads: the root's sort is the one serial step), then one queue of independent subtrees
-    // shared by the workers.
+    in_parts(0, count, threads, [&](long long from, long long to, int) {
+        for (long long i = from; i < to; ++i) order[i] = static_cast<int>(i);
+    });
+    // The top of the tree level by level, down to subtrees of < count/(4*threads) primitives: the ranges of a level are
+    // sorted side by side, each by its share of the threads (every sort is the std::sort call of the serial build on the
+    // same sequence, so ties fall the same way).  Then one queue of independent subtrees shared by the threads.
     const int defer_below = std::max(2, count / (4 * threads));
-    std::vector<Job> jobs;
-    std::mutex jobs_lock;
-    int fork_levels = 0;
-    while ((1 << (fork_levels + 1)) <= threads) ++fork_levels;
-    build.fill(0, 0, 0, count, &jobs, defer_below, fork_levels, &jobs_lock);
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= jobs.size()) break;
-            build.fill(jobs[i].node, jobs[i].axis, jobs[i].begin, jobs[i].end, nullptr, 0);
+    std::vector<Job> level{Job{0, 0, 0, count}}, next, jobs;
+    StageClock clock;
+    while (!level.empty()) {
+        const int ranges = static_cast<int>(level.size());
+        const int side_by_side = std::min(ranges, threads);
+        in_parts(0, ranges, side_by_side, [&](long long from, long long to, int) {
+            for (long long r = from; r < to; ++r) build.sort_range(level[r].axis, level[r].begin, level[r].end, std::max(1, threads / ranges));
+        });
+        next.clear();
+        for (const Job& j : level) {
+            const int mid = j.begin + (j.end - j.begin) / 2;
+            const int left = j.node + 1, right = j.node + 2 * (mid - j.begin);
+            build.set_inner(j.node, left, right);
+            const Job halves[2] = {Job{left, (j.axis + 1) % 3, j.begin, mid}, Job{right, (j.axis + 1) % 3, mid, j.end}};
+            for (const Job& h : halves) (h.end - h.begin < defer_below ? jobs : next).push_back(h);
         }
-    };
-    std::vector<std::thread> pool;
-    for (int i = 0; i < threads; ++i) pool.emplace_back(worker);
-    for (std::thread& t : pool) t.join();
+        level.swap(next);
+    }
+    clock.done("  upper levels sorted");
+    std::atomic<size_t> next_job{0};
+    in_parts(0, threads, threads, [&](long long, long long, int) {
+        for (;;) {
+            const size_t i = next_job.fetch_add(1);
+            if (i >= jobs.size()) break;
+            build.fill(jobs[i].node, jobs[i].axis, jobs[i].begin, jobs[i].end);
+        }
+    });
+    clock.done("  subtrees built");
     build.join_above(0, count, defer_below);
 }
 
@@ -167,10 +247,7 @@ void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads) 
 
 using namespace pt;
 
-static int default_build_threads() {
-    const unsigned n = std::thread::hardware_concurrency();
-    return static_cast<int>(n == 0 ? 1 : (n > 16 ? 16 : n));
-}
+static int default_build_threads() { return host_threads(); }
 
 extern "C" {
 

@@ -7,7 +7,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -223,6 +225,8 @@ namespace {
         if (e_ != hipSuccess) return pt::fail(PT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+typedef pt::UnfilledVector<PairNodeHost> PairNodes;
+
 struct DeviceBuffer {
     void* p = nullptr;
     ~DeviceBuffer() { if (p != nullptr) (void)hipFree(p); }
@@ -254,6 +258,67 @@ int upload(DeviceBuffer& buffer, const void* host, size_t bytes) {
     return PT_OK;
 }
 
+// Host arrays on their way to the device while the caller builds the next one: device memory is allocated at once (the
+// caller may store the address), the copy is made by a thread of the uploader's own, in the order of the calls.  An array
+// must stay as it is until finish() has returned.
+class Uploader {
+public:
+    explicit Uploader(int device) : device_(device) {}
+    ~Uploader() { (void)finish(); }
+    int send(DeviceBuffer& buffer, const void* host, size_t bytes) {
+        if (bytes == 0) return PT_OK;
+        HIP_TRY(hipMalloc(&buffer.p, bytes));
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            queue_.push_back(Copy{buffer.p, host, bytes});
+        }
+        if (!worker_.joinable()) worker_ = std::thread([this]() { run(); });
+        changed_.notify_one();
+        return PT_OK;
+    }
+    // Waits for every copy; reports the first one that failed.
+    int finish() {
+        if (worker_.joinable()) {
+            {
+                std::lock_guard<std::mutex> hold(lock_);
+                closed_ = true;
+            }
+            changed_.notify_one();
+            worker_.join();
+        }
+        const hipError_t e = failed_;
+        failed_ = hipSuccess;
+        closed_ = false;
+        if (e != hipSuccess) return pt::fail(PT_ERR_DEVICE, "copying a scene array to the device: %s", hipGetErrorString(e));
+        return PT_OK;
+    }
+
+private:
+    struct Copy { void* to; const void* from; size_t bytes; };
+    void run() {
+        hipError_t e = hipSetDevice(device_);
+        for (;;) {
+            Copy c;
+            {
+                std::unique_lock<std::mutex> hold(lock_);
+                changed_.wait(hold, [this]() { return !queue_.empty() || closed_; });
+                if (queue_.empty()) break;
+                c = queue_.front();
+                queue_.pop_front();
+            }
+            if (e == hipSuccess) e = hipMemcpy(c.to, c.from, c.bytes, hipMemcpyHostToDevice);
+        }
+        failed_ = e;
+    }
+    int device_;
+    std::mutex lock_;
+    std::condition_variable changed_;
+    std::deque<Copy> queue_;
+    bool closed_ = false;
+    hipError_t failed_ = hipSuccess;
+    std::thread worker_;
+};
+
 // Checks that `nodes` is a well-formed tree in the reference's layout over `primitive_count`
 // leaves (every primitive exactly once) and returns its height (leaf-only tree = 1).
 int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, int* height_out) {
@@ -283,7 +348,7 @@ int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, c
 }
 
 // Reference tree -> PairNode array (inner nodes numbered in pre-order).
-void flatten_tree(const PtBvhNode* nodes, int node_count, std::vector<PairNodeHost>* pairs, int32_t* root_ref) {
+void flatten_tree(const PtBvhNode* nodes, int node_count, PairNodes* pairs, int32_t* root_ref) {
     std::vector<int32_t> pair_of(node_count, -1);
     int32_t next = 0;
     for (int i = 0; i < node_count; ++i) {   // the reference numbers nodes in pre-order already
@@ -312,17 +377,7 @@ int search_height_cap() {
     return MAX_SEARCH_HEIGHT;
 }
 
-// PT_VERBOSE=1: seconds since the previous call, printed with what was done in them.
-struct StageClock {
-    const bool on = std::getenv("PT_VERBOSE") != nullptr;
-    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
-    void done(const char* what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "pathtracer_amd: %-46s %.3f s\n", what, std::chrono::duration<double>(now - last).count());
-        last = now;
-    }
-};
+using pt::StageClock;
 
 }  // namespace
 
@@ -353,28 +408,33 @@ struct PtScene {
 
 namespace {
 
+// `pairs_out` (if given) receives the binary hierarchy and must outlive `up`'s copies; so must `nodes`.
 int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, DeviceBuffer& pairs_buffer,
-               DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, std::vector<PairNodeHost>* pairs_out, bool rebuild) {
+               DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, PairNodes* pairs_out, bool rebuild, Uploader& up) {
     int height = 0;
     StageClock clock;
     int rc = validate_tree(nodes, node_count, primitive_count, what, &height);
     clock.done("reference tree checked");
     if (rc != PT_OK) return rc;
     if (height > STACK_DEPTH) return pt::fail(PT_ERR_UNSUPPORTED, "%s BVH is %d levels deep; the traversal stack holds %d", what, height, STACK_DEPTH);
+    rc = up.send(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
+    if (rc != PT_OK) return rc;
     static_assert(sizeof(PairNodeHost) == sizeof(PairNode), "host and device pair nodes must match");
-    std::vector<PairNodeHost> local_pairs;
-    std::vector<PairNodeHost>& pairs = pairs_out != nullptr ? *pairs_out : local_pairs;
+    PairNodes local_pairs;
+    PairNodes& pairs = pairs_out != nullptr ? *pairs_out : local_pairs;
     int32_t root = 0;
     bool rebuilt = false;
     if (rebuild && primitive_count > 2) {
         // The search hierarchy is this library's own (see sah_build.cpp); the reference's tree is
         // kept beside it for the exact traversal.  Leaf boxes are taken from the reference's leaves.
-        std::vector<PtAabb> boxes(primitive_count);
-        for (int i = 0; i < node_count; ++i) {
-            if (nodes[i].left == 0 && nodes[i].right == 0) boxes[nodes[i].index] = nodes[i].aabb;
-        }
+        pt::UnfilledVector<PtAabb> boxes(primitive_count);
+        pt::in_parts(0, node_count, node_count >= (1 << 16) ? pt::host_threads() : 1, [&](long long from, long long to, int) {
+            for (long long i = from; i < to; ++i) {
+                if (nodes[i].left == 0 && nodes[i].right == 0) boxes[nodes[i].index] = nodes[i].aabb;
+            }
+        });
         int sah_root = 0, sah_height = 0;
-        if (pt::build_sah_pairs(boxes, search_height_cap(), &pairs, &sah_root, &sah_height) == PT_OK) {
+        if (pt::build_sah_pairs(boxes.data(), primitive_count, search_height_cap(), &pairs, &sah_root, &sah_height) == PT_OK) {
             root = sah_root;
             height = sah_height;
             rebuilt = true;
@@ -385,11 +445,12 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
     if (!rebuilt) flatten_tree(nodes, node_count, &pairs, &root);
     clock.done(rebuilt ? "binary search hierarchy built (SAH)" : "reference tree flattened");
     *height_out = height;
-    rc = upload(pairs_buffer, pairs.data(), pairs.size() * sizeof(PairNode));
+    rc = up.send(pairs_buffer, pairs.data(), pairs.size() * sizeof(PairNode));
     if (rc != PT_OK) return rc;
-    rc = upload(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
-    if (rc != PT_OK) return rc;
-    clock.done("pair nodes and reference nodes uploaded");
+    if (pairs_out == nullptr) {
+        rc = up.finish();           // the pairs are this function's own
+        if (rc != PT_OK) return rc;
+    }
     tree->pairs = pairs_buffer.as<PairNode>();
     tree->ref_nodes = ref_buffer.as<PtBvhNode>();
     tree->root = root;
@@ -404,7 +465,13 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
 // built here instead, so that one search finds both nearest hits.  Skipped, leaving tri_quads null
 // (the exact-node path then serves the scene), when a coordinate is outside the range in which the
 // f32 slab products are guaranteed finite, or when there is no inner node at all.
-int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNodeHost>& tri_pairs, bool reference_topology, PtScene* scene) {
+// What build_search_nodes leaves on the host until the uploader has copied it.
+struct SearchStaging {
+    pt::UnfilledVector<PtAabb> own_boxes;
+    QuadHierarchy quads;
+};
+
+int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool reference_topology, PtScene* scene, SearchStaging* staging, Uploader& up) {
     DeviceScene& dev = scene->dev;
     dev.tri_quads = nullptr;
     dev.sphere_base = 0x7fffffff;
@@ -419,42 +486,54 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNodeHost>& tr
     for (int i = 0; i < d.sphere_count; ++i) proper_spheres = proper_spheres && d.spheres[i].radius >= 0.0;
     const bool merge = d.sphere_count > 1 && proper_spheres && !reference_topology && d.sphere_count + d.triangle_count > 2;
 
-    std::vector<PtAabb> own_boxes;       // every primitive's box exactly as the reference's BVH leaves store it
-    own_boxes.reserve(static_cast<size_t>(d.triangle_count) + (merge ? d.sphere_count : 0));
-    for (int i = 0; i < d.triangle_count; ++i) own_boxes.push_back(pt::box_of(d.triangles[i]));
-    if (merge) {
-        for (int i = 0; i < d.sphere_count; ++i) own_boxes.push_back(pt::box_of(d.spheres[i]));
-    }
+    StageClock clock;
+    pt::UnfilledVector<PtAabb>& own_boxes = staging->own_boxes;     // every primitive's box exactly as the reference's BVH leaves store it
+    const long long triangle_count = d.triangle_count, box_count = triangle_count + (merge ? d.sphere_count : 0);
+    own_boxes.resize(box_count);
     if (own_boxes.empty()) return PT_OK;
-    PtAabb all = own_boxes[0];
-    for (const PtAabb& b : own_boxes) {
-        all.min.x = pt::min_of(all.min.x, b.min.x); all.min.y = pt::min_of(all.min.y, b.min.y); all.min.z = pt::min_of(all.min.z, b.min.z);
-        all.max.x = pt::max_of(all.max.x, b.max.x); all.max.y = pt::max_of(all.max.y, b.max.y); all.max.z = pt::max_of(all.max.z, b.max.z);
-    }
-    const double extent[6] = {all.min.x, all.min.y, all.min.z, all.max.x, all.max.y, all.max.z};
     auto in_range = [](const PtAabb& b) {                       // false for NaN too
         return std::fabs(b.min.x) <= MAX_COORD32 && std::fabs(b.min.y) <= MAX_COORD32 && std::fabs(b.min.z) <= MAX_COORD32 &&
                std::fabs(b.max.x) <= MAX_COORD32 && std::fabs(b.max.y) <= MAX_COORD32 && std::fabs(b.max.z) <= MAX_COORD32;
     };
-    for (const PtAabb& b : own_boxes) {
-        if (!in_range(b)) return PT_OK;
+    const int team = box_count >= (1 << 16) ? pt::host_threads() : 1;
+    struct Piece { PtAabb all; bool in_range; };
+    std::vector<Piece> pieces(team);
+    pt::in_parts(0, box_count, team, [&](long long from, long long to, int part) {
+        Piece mine{PtAabb{}, true};
+        for (long long i = from; i < to; ++i) {
+            const PtAabb b = i < triangle_count ? pt::box_of(d.triangles[i]) : pt::box_of(d.spheres[i - triangle_count]);
+            own_boxes[i] = b;
+            if (i == from) mine.all = b;
+            mine.all.min.x = pt::min_of(mine.all.min.x, b.min.x); mine.all.min.y = pt::min_of(mine.all.min.y, b.min.y); mine.all.min.z = pt::min_of(mine.all.min.z, b.min.z);
+            mine.all.max.x = pt::max_of(mine.all.max.x, b.max.x); mine.all.max.y = pt::max_of(mine.all.max.y, b.max.y); mine.all.max.z = pt::max_of(mine.all.max.z, b.max.z);
+            mine.in_range = mine.in_range && in_range(b);
+        }
+        pieces[part] = mine;
+    });
+    PtAabb all = pieces[0].all;
+    for (const Piece& piece : pieces) {
+        const PtAabb& b = piece.all;
+        all.min.x = pt::min_of(all.min.x, b.min.x); all.min.y = pt::min_of(all.min.y, b.min.y); all.min.z = pt::min_of(all.min.z, b.min.z);
+        all.max.x = pt::max_of(all.max.x, b.max.x); all.max.y = pt::max_of(all.max.y, b.max.y); all.max.z = pt::max_of(all.max.z, b.max.z);
+        if (!piece.in_range) return PT_OK;
     }
+    const double extent[6] = {all.min.x, all.min.y, all.min.z, all.max.x, all.max.y, all.max.z};
     if (d.sphere_count == 1 && !in_range(pt::box_of(d.spheres[0]))) return PT_OK;    // the lone sphere's box is tested by the same kernel
+    clock.done("primitive boxes");
 
-    std::vector<PairNodeHost> merged_pairs;
-    const std::vector<PairNodeHost>* pairs = &tri_pairs;
+    PairNodes merged_pairs;
+    const PairNodes* pairs = &tri_pairs;
     if (merge) {
         int root = 0, height = 0;
-        if (pt::build_sah_pairs(own_boxes, search_height_cap(), &merged_pairs, &root, &height) != PT_OK) {
+        if (pt::build_sah_pairs(own_boxes.data(), static_cast<int>(box_count), search_height_cap(), &merged_pairs, &root, &height) != PT_OK) {
             pt::clear_error();
             return PT_OK;
         }
         pairs = &merged_pairs;
     }
     if (pairs->empty()) return PT_OK;
-    StageClock clock;
     static_assert(sizeof(QuadNode32Host) == sizeof(QuadNode32) && sizeof(QuadBoxes64Host) == sizeof(QuadBoxes64), "host and device four-wide nodes must match");
-    QuadHierarchy quads;
+    QuadHierarchy& quads = staging->quads;
     pt::collapse_to_quads(pairs->data(), pairs->size(), &quads);
     clock.done("collapsed to four-wide nodes");
     if (quads.nodes.size() > (size_t(1) << 25)) return PT_OK;   // the kernel addresses a node by a 32-bit byte offset
@@ -463,20 +542,13 @@ int build_search_nodes(const PtSceneDesc& d, const std::vector<PairNodeHost>& tr
         std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", own_boxes.size(),
                      merge ? " (triangles and spheres in one hierarchy)" : "", pairs->size(), quads.nodes.size(), scene->tri_stack_need);
     }
-    std::vector<LeafBox> leaf_boxes(own_boxes.size());
-    for (size_t i = 0; i < own_boxes.size(); ++i) {
-        const PtAabb& box = own_boxes[i];
-        double* b = leaf_boxes[i].box;
-        b[0] = box.min.x; b[1] = box.min.y; b[2] = box.min.z;
-        b[3] = box.max.x; b[4] = box.max.y; b[5] = box.max.z;
-    }
-    int rc = upload(scene->tri_quads, quads.nodes.data(), quads.nodes.size() * sizeof(QuadNode32));
+    static_assert(sizeof(LeafBox) == sizeof(PtAabb), "a leaf box on the device is the six doubles of PtAabb: min x, y, z, max x, y, z");
+    int rc = up.send(scene->tri_quads, quads.nodes.data(), quads.nodes.size() * sizeof(QuadNode32));
     if (rc != PT_OK) return rc;
-    rc = upload(scene->tri_quad_boxes, quads.exact.data(), quads.exact.size() * sizeof(QuadBoxes64));
+    rc = up.send(scene->tri_quad_boxes, quads.exact.data(), quads.exact.size() * sizeof(QuadBoxes64));
     if (rc != PT_OK) return rc;
-    rc = upload(scene->tri_leaf_boxes, leaf_boxes.data(), leaf_boxes.size() * sizeof(LeafBox));
+    rc = up.send(scene->tri_leaf_boxes, own_boxes.data(), own_boxes.size() * sizeof(LeafBox));
     if (rc != PT_OK) return rc;
-    clock.done("four-wide nodes, exact boxes, leaf boxes uploaded");
     dev.tri_quads = scene->tri_quads.as<QuadNode32>();
     dev.tri_quad_boxes = scene->tri_quad_boxes.as<QuadBoxes64>();
     dev.tri_boxes = scene->tri_leaf_boxes.as<LeafBox>();
@@ -786,46 +858,44 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
     std::unique_ptr<PtScene> scene(new PtScene());
     scene->device = device;
     int rc;
-    std::vector<PairNodeHost> pairs;
+    // Host arrays the uploader reads until up.finish(): declared before it, so that they outlive it on every way out.
+    PairNodes pairs;
+    pt::UnfilledVector<TriRecord> records;
+    SearchStaging staging;
+    Uploader up(device);
     if (d->triangle_count > 0) {
         rc = build_tree(d->triangle_bvh, d->triangle_bvh_node_count, d->triangle_count, "triangle", scene->tri_pairs, scene->tri_ref_nodes,
-                        &scene->dev.tri_tree, &scene->tri_height, &pairs, !tunables().reference_topology);
+                        &scene->dev.tri_tree, &scene->tri_height, &pairs, !tunables().reference_topology, up);
         if (rc != PT_OK) return rc;
         // ray-independent part of the triangle test, same operations as src/geometry.cpp:111-114, :124, :84-90
         StageClock clock;
-        std::vector<TriRecord> records(d->triangle_count);
-        const int threads = pt::host_threads();
-        std::vector<std::thread> team;
-        for (int part = 0; part < threads; ++part) {
-            team.emplace_back([&, part]() {
-                const long long n = d->triangle_count;
-                for (long long i = n * part / threads; i < n * (part + 1) / threads; ++i) {
-                    const PtTriangle& t = d->triangles[i];
-                    using namespace pt;
-                    const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
-                    const PtVec3 n3 = cross(ab, ac);
-                    const double nn = dot(n3, n3);
-                    const PtVec3 un = (1.0f / std::sqrt(nn)) * n3;
-                    TriRecord& r = records[i];
-                    r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
-                    r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
-                    r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
-                    r.nn = nn;
-                    r.un[0] = un.x; r.un[1] = un.y; r.un[2] = un.z;
-                    r.material = d->triangle_material_indices[i];
-                    for (int32_t& unused : r.pad_) unused = 0;
-                }
-            });
-        }
-        for (std::thread& t : team) t.join();
-        rc = upload(scene->tri_records, records.data(), records.size() * sizeof(TriRecord));
+        records.resize(d->triangle_count);
+        pt::in_parts(0, d->triangle_count, d->triangle_count >= (1 << 14) ? pt::host_threads() : 1, [&](long long from, long long to, int) {
+            for (long long i = from; i < to; ++i) {
+                const PtTriangle& t = d->triangles[i];
+                using namespace pt;
+                const PtVec3 ab = t.b - t.a, ac = t.c - t.a;
+                const PtVec3 n3 = cross(ab, ac);
+                const double nn = dot(n3, n3);
+                const PtVec3 un = (1.0f / std::sqrt(nn)) * n3;
+                TriRecord& r = records[i];
+                r.a[0] = t.a.x; r.a[1] = t.a.y; r.a[2] = t.a.z;
+                r.ab[0] = ab.x; r.ab[1] = ab.y; r.ab[2] = ab.z;
+                r.ac[0] = ac.x; r.ac[1] = ac.y; r.ac[2] = ac.z;
+                r.nn = nn;
+                r.un[0] = un.x; r.un[1] = un.y; r.un[2] = un.z;
+                r.material = d->triangle_material_indices[i];
+                for (int32_t& unused : r.pad_) unused = 0;
+            }
+        });
+        rc = up.send(scene->tri_records, records.data(), records.size() * sizeof(TriRecord));
         if (rc != PT_OK) return rc;
         scene->dev.tris = scene->tri_records.as<TriRecord>();
-        clock.done("triangle records made and uploaded");
+        clock.done("triangle records made");
     }
     if (d->sphere_count > 0) {
         rc = build_tree(d->sphere_bvh, d->sphere_bvh_node_count, d->sphere_count, "sphere", scene->sph_pairs, scene->sph_ref_nodes,
-                        &scene->dev.sph_tree, &scene->sph_height, nullptr, false);
+                        &scene->dev.sph_tree, &scene->sph_height, nullptr, false, up);
         if (rc != PT_OK) return rc;
         rc = upload(scene->spheres, d->spheres, sizeof(PtSphere) * d->sphere_count);
         if (rc != PT_OK) return rc;
@@ -834,8 +904,14 @@ int pt_scene_create(const PtSceneDesc* d, int32_t device, PtScene** out) {
         scene->dev.spheres = scene->spheres.as<double>();
         scene->dev.sph_material = scene->sph_material.as<int32_t>();
     }
-    rc = build_search_nodes(*d, pairs, tunables().reference_topology, scene.get());
+    rc = build_search_nodes(*d, pairs, tunables().reference_topology, scene.get(), &staging, up);
     if (rc != PT_OK) return rc;
+    {
+        StageClock clock;
+        rc = up.finish();
+        if (rc != PT_OK) return rc;
+        clock.done("waited for the copies to the device");
+    }
     scene->albedo_bounded = true;
     for (int i = 0; i < d->material_count; ++i) {
         const PtMaterial& m = d->materials[i];

@@ -3,9 +3,15 @@
 #ifndef PT_INTERNAL_H
 #define PT_INTERNAL_H
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/pathtracer_amd.h"
@@ -49,6 +55,48 @@ PtAabb box_of(const PtSphere& s);
 // Builds the 2N-1 node tree over `boxes` (src/bvh.cpp:20-58); `threads` > 1 builds disjoint subtrees concurrently.
 void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads);
 
+// Threads the host-side builders use: the machine's, at most 16 (PT_BUILD_THREADS overrides; results do not depend on it).
+int host_threads();
+
+// f(lo, hi, part) over [begin, end) cut into `parts` contiguous pieces, one thread each (the caller's included).
+template <class F>
+void in_parts(long long begin, long long end, int parts, F f) {
+    if (parts <= 1) { f(begin, end, 0); return; }
+    std::vector<std::thread> team;
+    const long long count = end - begin;
+    for (int t = 1; t < parts; ++t) {
+        team.emplace_back([=, &f]() { f(begin + count * t / parts, begin + count * (t + 1) / parts, t); });
+    }
+    f(begin, begin + count / parts, 0);
+    for (std::thread& t : team) t.join();
+}
+
+// std::allocator, except that resize() leaves trivially constructible elements unwritten: a large array that is about to
+// be filled by several threads then costs no pass of its own, and its pages are first touched by the threads that fill them.
+template <class T>
+struct UnfilledAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = UnfilledAllocator<U>; };
+    UnfilledAllocator() = default;
+    template <class U> UnfilledAllocator(const UnfilledAllocator<U>&) {}
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using UnfilledVector = std::vector<T, UnfilledAllocator<T>>;
+
+// PT_VERBOSE=1: seconds since the previous call, printed to stderr with what was done in them.
+struct StageClock {
+    const bool on = std::getenv("PT_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void done(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pathtracer_amd: %-46s %.3f s\n", what, std::chrono::duration<double>(now - last).count());
+        last = now;
+    }
+};
+
 PtMaterial lambertian(double r, double g, double b);
 PtMaterial metal(double r, double g, double b, double fuzziness);
 PtMaterial dielectric(double refraction_index);
@@ -62,9 +110,9 @@ struct PtHostScene {
     std::vector<PtSphere> spheres;
     std::vector<int32_t> sphere_material_indices;
     std::vector<PtBvhNode> sphere_bvh;
-    std::vector<PtTriangle> triangles;
-    std::vector<int32_t> triangle_material_indices;
-    std::vector<PtBvhNode> triangle_bvh;
+    pt::UnfilledVector<PtTriangle> triangles;
+    pt::UnfilledVector<int32_t> triangle_material_indices;
+    pt::UnfilledVector<PtBvhNode> triangle_bvh;
     PtColour background_start{0, 0, 0}, background_end{0, 0, 0};
     PtCamera camera{};
     double aspect_ratio = 1.0;

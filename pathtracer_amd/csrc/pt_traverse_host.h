@@ -4,7 +4,7 @@
 
 #include <vector>
 
-#include "../../include/pathtracer_amd.h"
+#include "pt_internal.h"
 
 namespace ptd {
 
@@ -29,8 +29,8 @@ static_assert(sizeof(QuadNode32Host) == 128, "QuadNode32Host mirrors QuadNode32"
 struct QuadBoxes64Host { double box[4][6]; };
 
 struct QuadHierarchy {
-    std::vector<QuadNode32Host> nodes;      // node 0 is the root
-    std::vector<QuadBoxes64Host> exact;
+    pt::UnfilledVector<QuadNode32Host> nodes;      // node 0 is the root
+    pt::UnfilledVector<QuadBoxes64Host> exact;
     int deepest_pending = 0;                // the most stack entries that can be waiting anywhere in a search
 };
 
@@ -38,11 +38,9 @@ struct QuadHierarchy {
 
 namespace pt {
 
-int host_threads();
-
 // Surface-area-heuristic hierarchy over `boxes` (one primitive per leaf, pre-order pair
 // numbering, height <= max_height).  *root_ref is a child reference (~0 for a single box).
-int build_sah_pairs(const std::vector<PtAabb>& boxes, int max_height, std::vector<ptd::PairNodeHost>* pairs, int* root_ref,
+int build_sah_pairs(const PtAabb* boxes, int count, int max_height, pt::UnfilledVector<ptd::PairNodeHost>* pairs, int* root_ref,
                     int* height_out);
 
 

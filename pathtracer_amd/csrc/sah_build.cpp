@@ -47,79 +47,77 @@ inline int levels_for(int count) {      // height of a balanced tree over `count
     return levels;
 }
 
-// f(lo, hi, part) over [begin, end) cut into `parts` contiguous pieces, one thread each (the caller's included).
-template <class F>
-void in_parts(int begin, int end, int parts, F f) {
-    if (parts <= 1) { f(begin, end, 0); return; }
-    std::vector<std::thread> team;
-    const long long count = end - begin;
-    for (int t = 1; t < parts; ++t) {
-        team.emplace_back([=, &f]() { f(begin + static_cast<int>(count * t / parts), begin + static_cast<int>(count * (t + 1) / parts), t); });
-    }
-    f(begin, begin + static_cast<int>(count / parts), 0);
-    for (std::thread& t : team) t.join();
-}
-
+constexpr int SPARSE_MAXIMUM = 64;        // ranges up to this long are swept over their occupied bins only
 constexpr int TEAM_MINIMUM = 1 << 18;     // ranges at least this long are binned and partitioned by several threads
 
 struct Bins {
     PtAabb box[3][MAX_BINS];
     int count[3][MAX_BINS];
     Bins() {
-        for (int a = 0; a < 3; ++a) for (int b = 0; b < MAX_BINS; ++b) { box[a][b] = empty_box(); count[a][b] = 0; }
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < BINS; ++b) { box[a][b] = empty_box(); count[a][b] = 0; }
     }
 };
 
+// A primitive as the builder moves it about: its box and its number.  The ranges of the recursion are contiguous
+// stretches of one array of these, so that binning and partitioning read and write memory in order.
+struct Item {
+    PtAabb box;
+    int id;
+    int pad_;
+};
+inline PtVec3 centroid_of(const PtAabb& b) { return PtVec3{0.5 * (b.min.x + b.max.x), 0.5 * (b.min.y + b.max.y), 0.5 * (b.min.z + b.max.z)}; }
+
 struct Builder {
-    const std::vector<PtAabb>& boxes;
-    std::vector<PtVec3> centroids;
-    std::vector<int> order;
-    std::vector<int> spare;              // partition buffer of the ranges that several threads split together
+    UnfilledVector<Item> items;
+    UnfilledVector<Item> spare;          // partition buffer of the ranges that several threads split together
     ptd::PairNodeHost* pairs;
     int max_height;
 
-    // Builds the subtree over order[begin, end) whose root pair (if any) is pairs[node];
-    // `level` is the depth of that root (tree root = 1).  Returns the child reference and box.
+    // Builds the subtree over items[begin, end) whose root pair (if any) is pairs[node];
+    // `level` is the depth of that root (tree root = 1).  Returns the child reference, the box and the subtree's height.
     // `threads` = how many threads this subtree may use: for its own split while it is long, then shared out
     // between its two sides.  The tree does not depend on it: every split is a function of the range as a set.
-    int build(int begin, int end, int node, int level, int threads, PtAabb* box_out) {
+    int build(int begin, int end, int node, int level, int threads, PtAabb* box_out, int* height_out) {
         const int count = end - begin;
         if (count == 1) {
-            *box_out = boxes[order[begin]];
-            return ~order[begin];
+            *box_out = items[begin].box;
+            *height_out = 1;
+            return ~items[begin].id;
         }
         const int team = (count >= TEAM_MINIMUM) ? threads : 1;
-        std::vector<PtAabb> part_bounds(team, empty_box());
-        in_parts(begin, end, team, [&](int lo, int hi, int part) {
+        PtAabb part_bounds[16];
+        in_parts(begin, end, team, [&](long long lo, long long hi, int part) {
             PtAabb b = empty_box();
-            for (int i = lo; i < hi; ++i) {
-                const PtVec3& c = centroids[order[i]];
+            for (long long i = lo; i < hi; ++i) {
+                const PtVec3 c = centroid_of(items[i].box);
                 grow(b, PtAabb{c, c});
             }
             part_bounds[part] = b;
         });
         PtAabb centroid_bounds = empty_box();
-        for (const PtAabb& b : part_bounds) grow(centroid_bounds, b);
+        for (int part = 0; part < team; ++part) grow(centroid_bounds, part_bounds[part]);
         const int mid = choose_split(begin, end, level, centroid_bounds, team);
         const int left_count = mid - begin;
         PtAabb left_box, right_box;
-        int left_ref, right_ref;
+        int left_ref, right_ref, left_height = 0, right_height = 0;
         if (threads > 1 && count > 65536) {
             const int left_threads = std::max(1, std::min(threads - 1, static_cast<int>(static_cast<long long>(threads) * left_count / count)));
-            std::thread other([&]() { left_ref = build(begin, mid, node + 1, level + 1, left_threads, &left_box); });
-            right_ref = build(mid, end, node + left_count, level + 1, threads - left_threads, &right_box);
+            std::thread other([&]() { left_ref = build(begin, mid, node + 1, level + 1, left_threads, &left_box, &left_height); });
+            right_ref = build(mid, end, node + left_count, level + 1, threads - left_threads, &right_box, &right_height);
             other.join();
         } else {
-            left_ref = build(begin, mid, node + 1, level + 1, 1, &left_box);
-            right_ref = build(mid, end, node + left_count, level + 1, 1, &right_box);
+            left_ref = build(begin, mid, node + 1, level + 1, 1, &left_box, &left_height);
+            right_ref = build(mid, end, node + left_count, level + 1, 1, &right_box, &right_height);
         }
         ptd::PairNodeHost& p = pairs[node];
         p.lbox = left_box;
         p.rbox = right_box;
         p.left = left_ref;
         p.right = right_ref;
+        for (int32_t& unused : p.pad_) unused = 0;
         *box_out = left_box;
         grow(*box_out, right_box);
+        *height_out = 1 + std::max(left_height, right_height);
         return node;
     }
 
@@ -128,7 +126,7 @@ struct Builder {
         return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
     }
 
-    // Partitions order[begin, end) and returns the split position (begin < mid < end).
+    // Partitions items[begin, end) and returns the split position (begin < mid < end).
     int choose_split(int begin, int end, int level, const PtAabb& cb, int team) {
         const int count = end - begin;
         const int levels_left = max_height - level;     // levels available below this node's children level
@@ -145,16 +143,48 @@ struct Builder {
             open[axis] = hi > lo[axis];
             scale[axis] = open[axis] ? BINS / (hi - lo[axis]) : 0.0;
         }
-        if (count > 2) {
+        if (count > 2 && count <= SPARSE_MAXIMUM) {
+            // A short range fills few of the bins.  Only a bin that holds something can be a new best split: at an empty
+            // bin the two sides are those of the bin before it, and an equal cost never replaces the best.  So the items
+            // are ordered by bin and the sweep visits the occupied bins only; sides, unions, areas and costs are the ones
+            // the dense sweep below forms (unions of boxes do not depend on the order they are formed in), at a cost
+            // that grows with the range instead of with the number of bins.
+            const Item* item = items.data() + begin;
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!open[axis]) continue;
+                int bin[SPARSE_MAXIMUM], by_bin[SPARSE_MAXIMUM];
+                double right_area[SPARSE_MAXIMUM + 1];
+                for (int i = 0; i < count; ++i) {
+                    bin[i] = bin_of(0.5 * (axis_of(item[i].box.min, axis) + axis_of(item[i].box.max, axis)), lo[axis], scale[axis]);
+                    int at = i;
+                    while (at > 0 && bin[by_bin[at - 1]] > bin[i]) { by_bin[at] = by_bin[at - 1]; --at; }
+                    by_bin[at] = i;
+                }
+                PtAabb acc = empty_box();
+                for (int k = count - 1; k >= 0; --k) {
+                    grow(acc, item[by_bin[k]].box);
+                    right_area[k] = half_area(acc);
+                }
+                acc = empty_box();
+                int k = 0;
+                while (k < count) {
+                    const int b = bin[by_bin[k]];
+                    while (k < count && bin[by_bin[k]] == b) grow(acc, item[by_bin[k++]].box);
+                    const int n = k, nr = count - k;
+                    if (nr == 0 || b >= BINS - 1 || !fits(n) || !fits(nr)) continue;
+                    const double cost = half_area(acc) * n + right_area[k] * nr;
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+        } else if (count > 2) {
             // all three axes in one pass over the range (bin boxes and counts are unions and sums: whoever
             // forms them, in whatever order, gets the same)
             std::vector<Bins> part_bins(team);
-            in_parts(begin, end, team, [&](int from, int to, int part) {
+            in_parts(begin, end, team, [&](long long from, long long to, int part) {
                 Bins& mine = part_bins[part];
-                for (int i = from; i < to; ++i) {
-                    const int id = order[i];
-                    const PtVec3& c = centroids[id];
-                    const PtAabb& box = boxes[id];
+                for (long long i = from; i < to; ++i) {
+                    const PtAabb& box = items[i].box;
+                    const PtVec3 c = centroid_of(box);
                     const int bx = bin_of(c.x, lo[0], scale[0]), by = bin_of(c.y, lo[1], scale[1]), bz = bin_of(c.z, lo[2], scale[2]);
                     ++mine.count[0][bx]; grow(mine.box[0][bx], box);
                     ++mine.count[1][by]; grow(mine.box[1][by], box);
@@ -194,44 +224,46 @@ struct Builder {
                 }
             }
         }
-        int* first = order.data() + begin;
-        int* last = order.data() + end;
+        Item* first = items.data() + begin;
+        Item* last = items.data() + end;
         if (best_axis >= 0) {
             const double axis_lo = lo[best_axis], axis_scale = scale[best_axis];
-            auto goes_left = [&](int id) { return bin_of(axis_of(centroids[id], best_axis), axis_lo, axis_scale) <= best_bin; };
+            const int axis = best_axis;
+            auto goes_left = [=](const Item& item) {
+                const double c = 0.5 * (axis_of(item.box.min, axis) + axis_of(item.box.max, axis));
+                return bin_of(c, axis_lo, axis_scale) <= best_bin;
+            };
             if (team <= 1) {
-                int* middle = std::partition(first, last, goes_left);
+                Item* middle = std::partition(first, last, goes_left);
                 return begin + static_cast<int>(middle - first);
             }
             // several threads: each counts its piece's left side, then copies its piece to its places in `spare`
-            std::vector<int> lefts(team + 1, 0), piece_begin(team + 1, end);
-            in_parts(begin, end, team, [&](int from, int to, int part) {
+            std::vector<int> lefts(team + 1, 0);
+            in_parts(begin, end, team, [&](long long from, long long to, int part) {
                 int n = 0;
-                for (int i = from; i < to; ++i) n += goes_left(order[i]) ? 1 : 0;
+                for (long long i = from; i < to; ++i) n += goes_left(items[i]) ? 1 : 0;
                 lefts[part + 1] = n;
-                piece_begin[part] = from;
             });
             for (int part = 0; part < team; ++part) lefts[part + 1] += lefts[part];
             const int total_left = lefts[team];
-            in_parts(begin, end, team, [&](int from, int to, int part) {
-                int l = begin + lefts[part];
-                int r = begin + total_left + (from - begin) - lefts[part];
-                for (int i = from; i < to; ++i) {
-                    const int id = order[i];
-                    if (goes_left(id)) spare[l++] = id; else spare[r++] = id;
+            in_parts(begin, end, team, [&](long long from, long long to, int part) {
+                long long l = begin + lefts[part];
+                long long r = begin + total_left + (from - begin) - lefts[part];
+                for (long long i = from; i < to; ++i) {
+                    if (goes_left(items[i])) spare[l++] = items[i]; else spare[r++] = items[i];
                 }
             });
-            in_parts(begin, end, team, [&](int from, int to, int) { std::copy(spare.begin() + from, spare.begin() + to, order.begin() + from); });
+            in_parts(begin, end, team, [&](long long from, long long to, int) { std::copy(spare.begin() + from, spare.begin() + to, items.begin() + from); });
             return begin + total_left;
         }
         // no acceptable binned split (coincident centroids, or the height cap): halve on the widest axis
         int axis = 0;
         const double ex = cb.max.x - cb.min.x, ey = cb.max.y - cb.min.y, ez = cb.max.z - cb.min.z;
         if (ey > ex && ey >= ez) axis = 1; else if (ez > ex && ez > ey) axis = 2;
-        int* middle = first + count / 2;
-        std::nth_element(first, middle, last, [&](int l, int r) {
-            const double a = axis_of(centroids[l], axis), b = axis_of(centroids[r], axis);
-            return a < b || (a == b && l < r);
+        Item* middle = first + count / 2;
+        std::nth_element(first, middle, last, [&](const Item& l, const Item& r) {
+            const double a = 0.5 * (axis_of(l.box.min, axis) + axis_of(l.box.max, axis)), b = 0.5 * (axis_of(r.box.min, axis) + axis_of(r.box.max, axis));
+            return a < b || (a == b && l.id < r.id);
         });
         return begin + count / 2;
     }
@@ -239,45 +271,27 @@ struct Builder {
 
 }  // namespace
 
-// Threads the host-side builders use: the machine's, at most 16 (PT_BUILD_THREADS overrides; results do not depend on it).
 int host_threads() {
-    if (const char* v = std::getenv("PT_BUILD_THREADS")) return std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("PT_BUILD_THREADS")) return std::min(16, std::max(1, std::atoi(v)));
     return static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
 }
 
-int build_sah_pairs(const std::vector<PtAabb>& boxes, int max_height, std::vector<ptd::PairNodeHost>* pairs, int* root_ref,
+int build_sah_pairs(const PtAabb* boxes, int count, int max_height, UnfilledVector<ptd::PairNodeHost>* pairs, int* root_ref,
                     int* height_out) {
     if (const char* v = std::getenv("PT_SAH_BINS")) BINS = std::min(MAX_BINS, std::max(2, std::atoi(v)));
-    const int count = static_cast<int>(boxes.size());
-    if (count == 0) return fail(PT_ERR_INVALID_ARGUMENT, "build_sah_pairs: no boxes");
+    if (count <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "build_sah_pairs: no boxes");
     if (levels_for(count) > max_height) return fail(PT_ERR_UNSUPPORTED, "%d leaves cannot fit a tree of height %d", count, max_height);
     pairs->resize(count > 1 ? count - 1 : 0);      // every pair is written in full by build()
-    Builder b{boxes, {}, {}, {}, pairs->data(), max_height};
-    b.centroids.resize(count);
-    b.order.resize(count);
+    Builder b{{}, {}, pairs->data(), max_height};
+    b.items.resize(count);
     if (count >= TEAM_MINIMUM) b.spare.resize(count);
-    for (int i = 0; i < count; ++i) {
-        b.centroids[i] = PtVec3{0.5 * (boxes[i].min.x + boxes[i].max.x), 0.5 * (boxes[i].min.y + boxes[i].max.y),
-                                0.5 * (boxes[i].min.z + boxes[i].max.z)};
-        b.order[i] = i;
-    }
     const int threads = host_threads();
+    in_parts(0, count, count >= TEAM_MINIMUM ? threads : 1, [&](long long from, long long to, int) {
+        for (long long i = from; i < to; ++i) b.items[i] = Item{boxes[i], static_cast<int>(i), 0};
+    });
     PtAabb root_box;
-    *root_ref = b.build(0, count, 0, 1, threads, &root_box);
-    // measured height (root pair = level 1, its leaf children = level 2, ...)
-    int height = 1;
-    if (count > 1) {
-        std::vector<std::pair<int, int>> todo{{0, 1}};
-        while (!todo.empty()) {
-            const auto [node, level] = todo.back();
-            todo.pop_back();
-            const ptd::PairNodeHost& p = (*pairs)[node];
-            for (int ref : {p.left, p.right}) {
-                height = std::max(height, level + 1);
-                if (ref >= 0) todo.emplace_back(ref, level + 1);
-            }
-        }
-    }
+    int height = 1;     // root pair = level 1, its leaf children = level 2, ...; a lone leaf counts as 1
+    *root_ref = b.build(0, count, 0, 1, threads, &root_box, &height);
     *height_out = height;
     return PT_OK;
 }
@@ -361,10 +375,11 @@ void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::Q
     out->deepest_pending = 0;
     if (pair_count == 0) return;
     const int threads = host_threads();
-    if (threads <= 1 || pair_count < (size_t(1) << 16)) {
+    if (pair_count < (size_t(1) << 16)) {
         Collapser{pairs, nullptr, 0, nullptr}.collapse(0, 0, out);
         return;
     }
+    StageClock clock;
     // leaves below every pair: children are numbered after their parent
     std::vector<int> leaves_below(pair_count);
     for (size_t i = pair_count; i-- > 0;) {
@@ -374,6 +389,7 @@ void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::Q
     // The top of the tree here; subtrees of at most 1/64 of the leaves are left as tasks, collapsed by the threads
     // into arrays of their own (indices from 0) and appended in the order they were met, so that the layout is the
     // same whatever the number of threads.
+    clock.done("  leaves counted");
     std::vector<QuadTask> tasks;
     Collapser{pairs, &leaves_below, std::max(1024, static_cast<int>((pair_count + 1) / 64)), &tasks}.collapse(0, 0, out);
     std::vector<ptd::QuadHierarchy> parts(tasks.size());
@@ -382,6 +398,7 @@ void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::Q
         const int stride = std::min<int>(threads, static_cast<int>(tasks.size()));
         for (size_t t = part; t < tasks.size(); t += stride) Collapser{pairs, nullptr, 0, nullptr}.collapse(tasks[t].pair, tasks[t].pending, &parts[t]);
     });
+    clock.done("  subtrees collapsed");
     std::vector<size_t> first(tasks.size() + 1, out->nodes.size());
     for (size_t t = 0; t < tasks.size(); ++t) first[t + 1] = first[t] + parts[t].nodes.size();
     out->nodes.resize(first[tasks.size()]);
@@ -402,6 +419,7 @@ void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::Q
             }
         }
     });
+    clock.done("  subtrees put in place");
 }
 
 }  // namespace pt

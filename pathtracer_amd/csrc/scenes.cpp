@@ -44,7 +44,7 @@ void append_transformed(const std::vector<PtTriangle>& model, const PtMat3& m, c
 }
 
 int finish(PtHostScene* scene) {
-    const int threads = static_cast<int>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    const int threads = host_threads();
     if (!scene->spheres.empty()) {
         std::vector<PtAabb> boxes;
         for (const PtSphere& s : scene->spheres) boxes.push_back(box_of(s));
@@ -52,10 +52,16 @@ int finish(PtHostScene* scene) {
         build_bvh(boxes, scene->sphere_bvh.data(), threads);
     }
     if (!scene->triangles.empty()) {
+        StageClock clock;
         std::vector<PtAabb> boxes(scene->triangles.size());
-        for (size_t i = 0; i < boxes.size(); ++i) boxes[i] = box_of(scene->triangles[i]);
+        in_parts(0, static_cast<long long>(boxes.size()), boxes.size() >= (1u << 16) ? host_threads() : 1, [&](long long from, long long to, int) {
+            for (long long i = from; i < to; ++i) boxes[i] = box_of(scene->triangles[i]);
+        });
+        clock.done("triangle boxes");
         scene->triangle_bvh.resize(2 * boxes.size() - 1);
+        clock.done("node array allocated");
         build_bvh(boxes, scene->triangle_bvh.data(), threads);
+        clock.done("reference-shaped BVH built");
     }
     return PT_OK;
 }
@@ -247,8 +253,10 @@ void chess_base_materials(PtHostScene* scene) {
 
 int build_chess32(const char* dir, bool mixed, int grid_n, PtHostScene* scene) {
     std::vector<PtTriangle> models[PIECE_KINDS];
+    StageClock clock;
     const int rc = load_pieces(dir, models);
     if (rc != PT_OK) return rc;
+    clock.done("piece models read");
     chess_base_materials(scene);
     if (mixed) {
         // every material type on some piece: kind -> slot M_FIRST_MIXED + 2*kind + colour
@@ -273,13 +281,30 @@ int build_chess32(const char* dir, bool mixed, int grid_n, PtHostScene* scene) {
         if (mixed) return M_FIRST_MIXED + 2 * kind + colour;
         return colour == 0 ? static_cast<int>(M_WHITE) : static_cast<int>(M_BLACK);
     };
+    // One set per board of the lattice, in row order; the sets are made by several threads, each into arrays of its own,
+    // and then put behind one another.
     const double pitch = 360.0f;
-    for (int gz = 0; gz < grid_n; ++gz) {
-        for (int gx = 0; gx < grid_n; ++gx) {
+    const int sets = grid_n * grid_n;
+    std::vector<PtHostScene> made(sets);
+    in_parts(0, sets, std::min(sets, host_threads()), [&](long long from, long long to, int) {
+        for (long long set = from; set < to; ++set) {
+            const int gz = static_cast<int>(set) / grid_n, gx = static_cast<int>(set) % grid_n;
             const PtVec3 origin{pitch * (gx - 0.5 * (grid_n - 1)), 0.0f, pitch * (gz - 0.5 * (grid_n - 1))};
-            append_chess_set(models, origin, material_of, scene);
+            append_chess_set(models, origin, material_of, &made[set]);
         }
-    }
+    });
+    std::vector<size_t> first(sets + 1, 0);
+    for (int set = 0; set < sets; ++set) first[set + 1] = first[set] + made[set].triangles.size();
+    scene->triangles.resize(first[sets]);
+    scene->triangle_material_indices.resize(first[sets]);
+    in_parts(0, sets, std::min(sets, host_threads()), [&](long long from, long long to, int) {
+        for (long long set = from; set < to; ++set) {
+            std::copy(made[set].triangles.begin(), made[set].triangles.end(), scene->triangles.begin() + first[set]);
+            std::copy(made[set].triangle_material_indices.begin(), made[set].triangle_material_indices.end(), scene->triangle_material_indices.begin() + first[set]);
+        }
+    });
+    made.clear();
+    clock.done("chess sets placed");
     scene->spheres = {PtSphere{PtVec3{120.0f * grid_n, 330.0f * grid_n, 60.0f * grid_n}, 140.0f * grid_n}};
     scene->sphere_material_indices = {M_LIGHT};
     set_camera(scene, PtVec3{0.0f, 180.0f * grid_n, 330.0f * grid_n}, PtVec3{0.0f, 10.0f, 0.0f}, 40.0f, 16.0 / 9.0);

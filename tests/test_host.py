@@ -5,6 +5,7 @@ nothing here touches a GPU.
 import ctypes as C
 import hashlib
 import os
+import subprocess
 import re
 
 import numpy as np
@@ -73,8 +74,28 @@ def test_bvh_build_structure_and_edge_cases(api, orc):
     # the threaded build (>= 32768 primitives) lands every node in the same slot as the serial one
     big = rng.uniform(-100, 100, (40000, 9))
     assert api.construct_triangle_bvh(big).tobytes() == orc.construct_triangle_bvh(big).tobytes()
+    # ranges of >= 65536 primitives are sorted by several threads together (partition steps of one std::sort dealt
+    # out): with keys from a small lattice almost every comparison is a tie, and the permutation must still be std::sort's
+    lattice = np.repeat(rng.integers(-12, 12, (150000, 1, 3)).astype(float), 3, axis=1) + rng.integers(0, 2, (150000, 3, 3))
+    tri = lattice.reshape(-1, 9)
+    assert api.construct_triangle_bvh(tri).tobytes() == orc.construct_triangle_bvh(tri).tobytes()
     with pytest.raises(api.PathTracerError):
         api.construct_triangle_bvh(np.zeros((0, 9)))
+
+
+def test_host_builders_do_not_depend_on_the_thread_count():
+    """The reference-shaped BVH, the search hierarchy and its four-wide form of the chess set (422,598 triangles: long enough
+    for every several-threads-on-one-range path) built by 1, 3 and 8 threads: the same bytes."""
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "consumer", "hierarchy_digest")
+    assert os.path.exists(tool), "run `make` first"
+    lines = set()
+    for threads in (1, 3, 8):
+        done = subprocess.run([tool, str(abi.PT_SCENE_CHESS32), MODELS], env=dict(os.environ, PT_BUILD_THREADS=str(threads)),
+                              capture_output=True, text=True, timeout=300)
+        assert done.returncode == 0, done.stderr
+        lines.add(done.stdout)
+    assert len(lines) == 1, lines
+    assert "reference nodes 845195" in lines.pop()
 
 
 def test_camera_and_frame(api, orc, golden):
