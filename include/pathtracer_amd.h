@@ -211,7 +211,13 @@ int pt_write_ppm_file(const char* filename, const uint8_t* bgra, int32_t width, 
 
 /* Copies the scene (src/path_tracing.h:9-22) into the HBM of `device` and lays
  * the BVH out for traversal.  Validates every index the reference would follow
- * blindly.  The caller keeps ownership of the arrays in *desc. */
+ * blindly.  The caller keeps ownership of the arrays in *desc.
+ * The trees in *desc are the reference's to the letter: results are those of the reference's
+ * traversal of exactly these nodes.  A tree built by pt_construct_*_bvh over proper primitives has
+ * boxes that nest (every inner box holds its children's) and is searched through a faster
+ * hierarchy of the library's own, which reaches the same leaves.  A tree whose boxes do not nest
+ * (a hollow sphere's inverted box, src/geometry.cpp:51-57, or a caller's own inner boxes) is
+ * walked as it is, without skipping anything for being far: same bytes, lower speed. */
 int pt_scene_create(const PtSceneDesc* desc, int32_t device, PtScene** out);
 void pt_scene_destroy(PtScene* scene);
 

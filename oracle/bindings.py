@@ -213,10 +213,11 @@ class _CpuLib:
         return out
 
     # ---- scenes
-    def scene_create(self, arrays):
+    def scene_create(self, arrays, own_trees=True):
         """arrays: dict with materials, spheres, sphere_material_indices, triangles,
-        triangle_material_indices, background (2x3); BVHs are built by the checker itself."""
-        desc, keep = make_desc(arrays, with_bvh=False)
+        triangle_material_indices, background (2x3); BVHs are built by the checker itself, unless
+        `own_trees` is False: then the trees in `arrays` are traversed as they are."""
+        desc, keep = make_desc(arrays, with_bvh=not own_trees)
         handle = self._call("scene_create")(C.byref(desc))
         del keep
         if not handle:

@@ -648,13 +648,16 @@ OrcScene* orc_scene_create(const PtSceneDesc* d) {
         s->spheres.assign(d->spheres, d->spheres + d->sphere_count);
         s->sphere_material.assign(d->sphere_material_indices, d->sphere_material_indices + d->sphere_count);
         s->sphere_nodes.resize(2 * d->sphere_count - 1);
-        orc_construct_sphere_bvh(s->spheres.data(), d->sphere_count, s->sphere_nodes.data());
+        // a tree that comes with the description is traversed as it is (the reference's Scene only points at one: path_tracing.h:9-22)
+        if (d->sphere_bvh != nullptr && d->sphere_bvh_node_count == 2 * d->sphere_count - 1) std::memcpy(s->sphere_nodes.data(), d->sphere_bvh, s->sphere_nodes.size() * sizeof(PtBvhNode));
+        else orc_construct_sphere_bvh(s->spheres.data(), d->sphere_count, s->sphere_nodes.data());
     }
     if (d->triangle_count > 0) {
         s->triangles.assign(d->triangles, d->triangles + d->triangle_count);
         s->triangle_material.assign(d->triangle_material_indices, d->triangle_material_indices + d->triangle_count);
         s->triangle_nodes.resize(2 * d->triangle_count - 1);
-        orc_construct_triangle_bvh(s->triangles.data(), d->triangle_count, s->triangle_nodes.data());
+        if (d->triangle_bvh != nullptr && d->triangle_bvh_node_count == 2 * d->triangle_count - 1) std::memcpy(s->triangle_nodes.data(), d->triangle_bvh, s->triangle_nodes.size() * sizeof(PtBvhNode));
+        else orc_construct_triangle_bvh(s->triangles.data(), d->triangle_count, s->triangle_nodes.data());
     }
     s->bg0 = V3{d->background_gradient_start.r, d->background_gradient_start.g, d->background_gradient_start.b};
     s->bg1 = V3{d->background_gradient_end.r, d->background_gradient_end.g, d->background_gradient_end.b};

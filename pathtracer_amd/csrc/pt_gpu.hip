@@ -321,12 +321,19 @@ private:
 
 // Checks that `nodes` is a well-formed tree in the reference's layout over `primitive_count`
 // leaves (every primitive exactly once) and returns its height (leaf-only tree = 1).
-int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, int* height_out) {
+// *nested_out: every box has min <= max (false for NaN) and every inner box contains both children's boxes.
+int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, int* height_out, bool* nested_out) {
     if (node_count != 2 * primitive_count - 1) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: %d nodes for %d primitives, expected %d", what, node_count, primitive_count, 2 * primitive_count - 1);
     std::vector<char> seen_node(node_count, 0), seen_primitive(primitive_count, 0);
     std::vector<std::pair<int, int>> todo;   // node, depth
     todo.emplace_back(0, 1);
     int height = 0;
+    bool nested = true;
+    auto upright = [](const PtAabb& b) { return b.min.x <= b.max.x && b.min.y <= b.max.y && b.min.z <= b.max.z; };
+    auto holds = [](const PtAabb& outer, const PtAabb& inner) {
+        return outer.min.x <= inner.min.x && outer.min.y <= inner.min.y && outer.min.z <= inner.min.z &&
+               outer.max.x >= inner.max.x && outer.max.y >= inner.max.y && outer.max.z >= inner.max.z;
+    };
     while (!todo.empty()) {
         const auto [i, depth] = todo.back();
         todo.pop_back();
@@ -334,16 +341,19 @@ int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, c
         seen_node[i] = 1;
         height = std::max(height, depth);
         const PtBvhNode& n = nodes[i];
+        nested = nested && upright(n.aabb);
         if (n.left == 0 && n.right == 0) {
             if (n.index < 0 || n.index >= primitive_count || seen_primitive[n.index]) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: leaf %d names primitive %d (out of range or repeated)", what, i, n.index);
             seen_primitive[n.index] = 1;
         } else {
             if (n.left <= 0 || n.right <= 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: node %d has one child only", what, i);
+            if (n.left < node_count && n.right < node_count) nested = nested && holds(n.aabb, nodes[n.left].aabb) && holds(n.aabb, nodes[n.right].aabb);
             todo.emplace_back(n.right, depth + 1);
             todo.emplace_back(n.left, depth + 1);
         }
     }
     *height_out = height;
+    *nested_out = nested;
     return PT_OK;
 }
 
@@ -413,9 +423,12 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
                DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, PairNodes* pairs_out, bool rebuild, Uploader& up) {
     int height = 0;
     StageClock clock;
-    int rc = validate_tree(nodes, node_count, primitive_count, what, &height);
+    bool nested = false;
+    int rc = validate_tree(nodes, node_count, primitive_count, what, &height, &nested);
     clock.done("reference tree checked");
     if (rc != PT_OK) return rc;
+    // Boxes that do not nest: which leaves the reference reaches depends on this very tree, so it is searched as it is.
+    rebuild = rebuild && nested;
     if (height > STACK_DEPTH) return pt::fail(PT_ERR_UNSUPPORTED, "%s BVH is %d levels deep; the traversal stack holds %d", what, height, STACK_DEPTH);
     rc = up.send(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
     if (rc != PT_OK) return rc;
@@ -455,6 +468,8 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
     tree->ref_nodes = ref_buffer.as<PtBvhNode>();
     tree->root = root;
     tree->count = primitive_count;
+    tree->nested = nested ? 1 : 0;
+    tree->pad_ = 0;
     std::memcpy(tree->root_box, &nodes[0].aabb, 48);
     return PT_OK;
 }
@@ -484,7 +499,9 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     // library's hierarchy; the reference's sphere tree is walked as it is.
     bool proper_spheres = true;
     for (int i = 0; i < d.sphere_count; ++i) proper_spheres = proper_spheres && d.spheres[i].radius >= 0.0;
-    const bool merge = d.sphere_count > 1 && proper_spheres && !reference_topology && d.sphere_count + d.triangle_count > 2;
+    const bool sphere_tree_nests = d.sphere_count == 0 || dev.sph_tree.nested != 0;
+    const bool merge = d.sphere_count > 1 && proper_spheres && sphere_tree_nests && !reference_topology && d.sphere_count + d.triangle_count > 2;
+    if (d.triangle_count > 0 && dev.tri_tree.nested == 0) return PT_OK;     // the caller's triangle tree is searched as it is
 
     StageClock clock;
     pt::UnfilledVector<PtAabb>& own_boxes = staging->own_boxes;     // every primitive's box exactly as the reference's BVH leaves store it
@@ -798,6 +815,14 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     return PT_OK;
 }
 
+// Scenes the wavefront kernel renders (any other goes through the one-lane-per-pixel kernel): bounded albedos (see
+// pt_wavefront.hpp), trees no deeper than its stacks, and a triangle tree whose boxes nest (its node steps skip what is
+// entered beyond the best hit; a sphere tree that does not nest is walked without skipping, see TreeRef::nested).
+bool wavefront_serves(const PtScene* scene) {
+    return scene->albedo_bounded && !tunables().force_pixels_kernel && scene->tri_height <= MAX_WF_STACK_SLOTS &&
+           scene->sph_height <= MAX_WF_STACK_SLOTS && (scene->dev.tri_tree.count == 0 || scene->dev.tri_tree.nested != 0);
+}
+
 int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream, Workspace ws) {
     if (frame->row_begin == frame->row_end || frame->sample_count == 0 || grid_blocks(*frame) == 0) return PT_OK;
     HIP_TRY(hipSetDevice(scene->device));
@@ -817,8 +842,7 @@ int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hi
     HIP_TRY(hipEventRecord(scene->start, stream));
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
-    const bool wavefront = scene->albedo_bounded && frame->max_bounces >= 1 && !tunables().force_pixels_kernel &&
-                           scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS;
+    const bool wavefront = frame->max_bounces >= 1 && wavefront_serves(scene);
     const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream, ws) : launch_pixels_kernel(scene, frame, accum_device, stream);
     if (rc != PT_OK) return rc;
     HIP_TRY(hipEventRecord(scene->stop, stream));
@@ -1044,8 +1068,7 @@ int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_inde
     // The indices come from the kernel that renders: the persistent wavefront kernel, run over the frame's
     // rows for one sample and one vertex per path with its two searches kept from shortening each other.
     // Scenes (and PT_KERNEL=pixels) that render with the one-lane-per-pixel kernel use that kernel's search.
-    const bool wavefront = scene->albedo_bounded && !tunables().force_pixels_kernel &&
-                           scene->tri_height <= MAX_WF_STACK_SLOTS && scene->sph_height <= MAX_WF_STACK_SLOTS;
+    const bool wavefront = wavefront_serves(scene);
     if (wavefront) {
         PtFrame one = *frame;
         one.sample_count = 1;

@@ -23,6 +23,11 @@ struct TreeRef {
     const PtBvhNode* ref_nodes;   // the reference's own node array, for the exhaustive path
     int32_t root;                 // child-reference encoding; `count == 0` means "no tree"
     int32_t count;
+    int32_t nested;               // every box has min <= max and every inner box contains its children's: only then may a
+                                  // subtree be skipped because its box is entered beyond the best hit.  The reference's own
+                                  // build gives such a tree unless a sphere is hollow (negative radius: inverted box,
+                                  // src/geometry.cpp:51-57); a caller's tree is taken as it is.
+    int32_t pad_;
     double root_box[6];
 };
 
@@ -261,6 +266,10 @@ template <class Leaf>
 PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Leaf& leaf, double limit, int* stack /* [level*BLOCK_THREADS] */, bool& tie) {
     Hit best{-1, REAL_MAX};
     tie = false;
+    // In a tree whose boxes do not nest, a leaf can lie outside the boxes above it: what the reference reaches is then
+    // decided by those boxes alone, whatever the distances, and nothing may be skipped for being far.
+    const bool prune = tree.nested != 0;
+    if (!prune) limit = REAL_MAX;
     double cut = prune_cut(limit);
     {
         double tmin, tmax;
@@ -273,7 +282,7 @@ PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Lea
             if (d < best.distance) {
                 best = Hit{primitive, d};
                 tie = false;
-                if (d < limit) {
+                if (prune && d < limit) {
                     limit = d;
                     cut = prune_cut(limit);
                 }
