@@ -188,3 +188,44 @@ def test_random_scenes_against_the_checker(api, orc, seed):
     size = (int(rng.integers(9, 70)), int(rng.integers(9, 50)))
     _compare(api, orc, arrays, eye, (0.0, 0.0, 0.0), size=size, spp=int(rng.integers(1, 4)), bounces=int(rng.choice([1, 4, 12, 50])),
              aperture=float(rng.choice([0.0, 0.05, 0.6])))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_RANDOM_FRAMES", "12"))))
+def test_random_frames_against_the_checker(api, orc, seed):
+    """Seeded random *frames* over a small random scene: odd sizes, row ranges that start anywhere, shards, sample ranges that
+    start anywhere and span several groups of 16, any depth (0 = the one-lane-per-pixel kernel), one group per launch or all
+    at once, both kernels, into a buffer that already holds numbers.  Every double against the CPU checker.
+    PT_RANDOM_FRAMES=<n> widens the campaign."""
+    from oracle.bindings import make_desc
+    rng = np.random.default_rng(5000 + seed)
+    count = int(rng.choice([3, 40, 300]))
+    triangles = (rng.uniform(-7, 7, (count, 1, 3)) + rng.normal(0, rng.uniform(0.3, 2.5), (count, 3, 3))).reshape(-1, 9)
+    n = int(rng.choice([0, 1, 6]))
+    spheres = np.concatenate([rng.uniform(-7, 7, (n, 3)), rng.uniform(0.3, 2.0, (n, 1))], 1) if n else None
+    arrays = _scene(api, triangles, spheres, tri_materials=rng.integers(0, 4, count), sph_materials=None if spheres is None else rng.integers(0, 4, n))
+    desc, keep = make_desc(arrays)
+    device = api.DeviceScene(desc, keepalive=keep)
+    checker = orc.scene_create(arrays)
+    width, height = int(rng.integers(2, 150)), int(rng.integers(2, 90))
+    cam = api.camera_look_at(tuple(rng.uniform(10, 24, 3) * rng.choice([-1, 1], 3)), (0.0, 0.0, 0.0), 0.7, float(rng.choice([0.0, 0.1])))
+    rows = sorted(int(v) for v in rng.integers(0, height + 1, 2))
+    if rows[0] == rows[1]:
+        rows = [0, height]
+    shards = int(rng.choice([1, 1, 2, 3, 5]))
+    frame = api.camera_frame(cam, width / height, width, height, row_begin=rows[0], row_end=rows[1],
+                             sample_begin=int(rng.integers(0, 40)), sample_count=int(rng.choice([1, 5, 16, 17, 33, 50])),
+                             max_bounces=int(rng.choice([0, 1, 3, 12, 50])), shard_count=shards, shard_index=int(rng.integers(0, shards)))
+    held = rng.uniform(0, 3, 4 * width * height)
+    saved = {k: os.environ.pop(k, None) for k in ("PT_WORKSPACE_GB", "PT_KERNEL")}
+    try:
+        if seed % 2 == 1:
+            os.environ["PT_WORKSPACE_GB"] = "0"          # one sample group per launch
+        if seed % 7 == 3:
+            os.environ["PT_KERNEL"] = "pixels"
+        got = device.render(frame, held.copy())
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert same_bits(got, checker.render(frame, held.copy(), threads=4))
