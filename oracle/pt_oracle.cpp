@@ -392,7 +392,9 @@ V3 trace_path(const OrcScene& s, Ray ray, int max_bounces, Counters* k, bool che
         if (hs.index != -1 || ht.index != -1) {
             V3 p, n;
             const PtMaterial* m;
-            if (hs.distance < ht.distance) {                                         // :183
+            // ht.index == -1 with hs.distance not below REAL_MAX (a sphere "hit" at infinity: r * r overflowed): the reference's
+            // assert stops it at :196; the checker, like the library, lets the sphere have the vertex
+            if (hs.distance < ht.distance || ht.index == -1) {                       // :183
                 const PtSphere& sp = s.spheres[hs.index];
                 p = add(ray.o, scale(hs.distance, ray.d));
                 const double sign = (sp.radius < 0.0f) ? -1.0f : 1.0f;               // :190

@@ -243,11 +243,19 @@ void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads) 
     build.join_above(0, count, defer_below);
 }
 
+bool sortable(const std::vector<PtAabb>& boxes) {
+    for (const PtAabb& b : boxes) {
+        if (b.min.x != b.min.x || b.min.y != b.min.y || b.min.z != b.min.z) return false;
+    }
+    return true;
+}
+
 }  // namespace pt
 
 using namespace pt;
 
 static int default_build_threads() { return host_threads(); }
+
 
 extern "C" {
 
@@ -255,6 +263,7 @@ int pt_construct_triangle_bvh(const PtTriangle* triangles, int32_t count, PtBvhN
     if (triangles == nullptr || nodes == nullptr || count <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_construct_triangle_bvh: need count > 0 and non-null arrays");
     std::vector<PtAabb> boxes(count);
     for (int32_t i = 0; i < count; ++i) boxes[i] = box_of(triangles[i]);
+    if (!sortable(boxes)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_construct_triangle_bvh: a triangle has a NaN coordinate (the reference sorts box minima with std::sort, which is undefined for unordered keys)");
     build_bvh(boxes, nodes, default_build_threads());
     return PT_OK;
 }
@@ -263,6 +272,7 @@ int pt_construct_sphere_bvh(const PtSphere* spheres, int32_t count, PtBvhNode* n
     if (spheres == nullptr || nodes == nullptr || count <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "pt_construct_sphere_bvh: need count > 0 and non-null arrays");
     std::vector<PtAabb> boxes(count);
     for (int32_t i = 0; i < count; ++i) boxes[i] = box_of(spheres[i]);
+    if (!sortable(boxes)) return fail(PT_ERR_INVALID_ARGUMENT, "pt_construct_sphere_bvh: a sphere has a NaN centre or radius (the reference sorts box minima with std::sort, which is undefined for unordered keys)");
     build_bvh(boxes, nodes, default_build_threads());
     return PT_OK;
 }

@@ -147,8 +147,10 @@ __global__ void eval_kernel(int op, const void* __restrict__ in, long long n, vo
         const D3 inv{1.0f / r[3], 1.0f / r[4], 1.0f / r[5]};
         double tmin, tmax;
         slab_exact(D3{r[0], r[1], r[2]}, inv, r + 6, tmin, tmax);
-        if (isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z)) {
-            // the fast form must agree wherever it is allowed to run (zeros may differ in sign)
+        bool bounded = true;
+        for (int k = 0; k < 12; ++k) bounded = bounded && isfinite(r[k]);
+        if (bounded && isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z)) {
+            // the short form must agree wherever it is allowed to run: finite reciprocals, origin and box (zeros may differ in sign)
             double fmin_, fmax_;
             slab_finite(D3{r[0], r[1], r[2]}, inv, r[6], r[7], r[8], r[9], r[10], r[11], fmin_, fmax_);
             if (!(fmin_ == tmin && fmax_ == tmax)) { tmin = __builtin_nan(""); tmax = __builtin_nan(""); }
@@ -322,13 +324,17 @@ private:
 // Checks that `nodes` is a well-formed tree in the reference's layout over `primitive_count`
 // leaves (every primitive exactly once) and returns its height (leaf-only tree = 1).
 // *nested_out: every box has min <= max (false for NaN) and every inner box contains both children's boxes.
-int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, int* height_out, bool* nested_out) {
+// *finite_out: no box holds an infinity or a NaN.
+int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, const char* what, int* height_out, bool* nested_out, bool* finite_out) {
     if (node_count != 2 * primitive_count - 1) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: %d nodes for %d primitives, expected %d", what, node_count, primitive_count, 2 * primitive_count - 1);
     std::vector<char> seen_node(node_count, 0), seen_primitive(primitive_count, 0);
     std::vector<std::pair<int, int>> todo;   // node, depth
     todo.emplace_back(0, 1);
     int height = 0;
-    bool nested = true;
+    bool nested = true, finite = true;
+    auto bounded = [](const PtAabb& b) {
+        return std::isfinite(b.min.x) && std::isfinite(b.min.y) && std::isfinite(b.min.z) && std::isfinite(b.max.x) && std::isfinite(b.max.y) && std::isfinite(b.max.z);
+    };
     auto upright = [](const PtAabb& b) { return b.min.x <= b.max.x && b.min.y <= b.max.y && b.min.z <= b.max.z; };
     auto holds = [](const PtAabb& outer, const PtAabb& inner) {
         return outer.min.x <= inner.min.x && outer.min.y <= inner.min.y && outer.min.z <= inner.min.z &&
@@ -342,6 +348,7 @@ int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, c
         height = std::max(height, depth);
         const PtBvhNode& n = nodes[i];
         nested = nested && upright(n.aabb);
+        finite = finite && bounded(n.aabb);
         if (n.left == 0 && n.right == 0) {
             if (n.index < 0 || n.index >= primitive_count || seen_primitive[n.index]) return pt::fail(PT_ERR_INVALID_ARGUMENT, "%s BVH: leaf %d names primitive %d (out of range or repeated)", what, i, n.index);
             seen_primitive[n.index] = 1;
@@ -354,6 +361,7 @@ int validate_tree(const PtBvhNode* nodes, int node_count, int primitive_count, c
     }
     *height_out = height;
     *nested_out = nested;
+    *finite_out = finite;
     return PT_OK;
 }
 
@@ -423,12 +431,13 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
                DeviceBuffer& ref_buffer, TreeRef* tree, int* height_out, PairNodes* pairs_out, bool rebuild, Uploader& up) {
     int height = 0;
     StageClock clock;
-    bool nested = false;
-    int rc = validate_tree(nodes, node_count, primitive_count, what, &height, &nested);
+    bool nested = false, finite = false;
+    int rc = validate_tree(nodes, node_count, primitive_count, what, &height, &nested, &finite);
     clock.done("reference tree checked");
     if (rc != PT_OK) return rc;
     // Boxes that do not nest: which leaves the reference reaches depends on this very tree, so it is searched as it is.
-    rebuild = rebuild && nested;
+    // Unbounded boxes have no centroid to sort by: their tree is kept too.
+    rebuild = rebuild && nested && finite;
     if (height > STACK_DEPTH) return pt::fail(PT_ERR_UNSUPPORTED, "%s BVH is %d levels deep; the traversal stack holds %d", what, height, STACK_DEPTH);
     rc = up.send(ref_buffer, nodes, static_cast<size_t>(node_count) * sizeof(PtBvhNode));
     if (rc != PT_OK) return rc;
@@ -469,7 +478,7 @@ int build_tree(const PtBvhNode* nodes, int node_count, int primitive_count, cons
     tree->root = root;
     tree->count = primitive_count;
     tree->nested = nested ? 1 : 0;
-    tree->pad_ = 0;
+    tree->bounded = finite ? 1 : 0;
     std::memcpy(tree->root_box, &nodes[0].aabb, 48);
     return PT_OK;
 }
@@ -816,11 +825,13 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
 }
 
 // Scenes the wavefront kernel renders (any other goes through the one-lane-per-pixel kernel): bounded albedos (see
-// pt_wavefront.hpp), trees no deeper than its stacks, and a triangle tree whose boxes nest (its node steps skip what is
-// entered beyond the best hit; a sphere tree that does not nest is walked without skipping, see TreeRef::nested).
+// pt_wavefront.hpp), trees no deeper than its stacks, and a triangle tree whose boxes nest and are finite (its node steps
+// skip what is entered beyond the best hit and use the short form of the slab test; a sphere tree of another kind is
+// walked without skipping and with the exact form, see TreeRef).
 bool wavefront_serves(const PtScene* scene) {
+    const TreeRef& triangles = scene->dev.tri_tree;
     return scene->albedo_bounded && !tunables().force_pixels_kernel && scene->tri_height <= MAX_WF_STACK_SLOTS &&
-           scene->sph_height <= MAX_WF_STACK_SLOTS && (scene->dev.tri_tree.count == 0 || scene->dev.tri_tree.nested != 0);
+           scene->sph_height <= MAX_WF_STACK_SLOTS && (triangles.count == 0 || (triangles.nested != 0 && triangles.bounded != 0));
 }
 
 int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream, Workspace ws) {

@@ -54,6 +54,9 @@ PtAabb box_of(const PtTriangle& t);
 PtAabb box_of(const PtSphere& s);
 // Builds the 2N-1 node tree over `boxes` (src/bvh.cpp:20-58); `threads` > 1 builds disjoint subtrees concurrently.
 void build_bvh(const std::vector<PtAabb>& boxes, PtBvhNode* nodes, int threads);
+// The sort keys of that build (src/bvh.cpp:33-38) are the box minima: false if one is a NaN, which has no place in any
+// order (std::sort is undefined then, in the reference as here).
+bool sortable(const std::vector<PtAabb>& boxes);
 
 // Threads the host-side builders use: the machine's, at most 16 (PT_BUILD_THREADS overrides; results do not depend on it).
 int host_threads();

@@ -27,7 +27,8 @@ struct TreeRef {
                                   // subtree be skipped because its box is entered beyond the best hit.  The reference's own
                                   // build gives such a tree unless a sphere is hollow (negative radius: inverted box,
                                   // src/geometry.cpp:51-57); a caller's tree is taken as it is.
-    int32_t pad_;
+    int32_t bounded;              // no box holds an infinity or a NaN: only then is the short form of the slab test
+                                  // (hardware min/max) sure to meet no NaN product and to equal the reference's selections
     double root_box[6];
 };
 
@@ -271,9 +272,16 @@ PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Lea
     const bool prune = tree.nested != 0;
     if (!prune) limit = REAL_MAX;
     double cut = prune_cut(limit);
+    // A box with an infinity or a NaN can make a slab product NaN, and then the order in which the reference's std::min /
+    // std::max take their arguments decides what the test returns.
+    const bool short_form = tree.bounded != 0;
+    auto slab = [&](const double* box, double& tmin, double& tmax) {
+        if (short_form) slab_finite(ray.o, inv, box[0], box[1], box[2], box[3], box[4], box[5], tmin, tmax);
+        else slab_exact(ray.o, inv, box, tmin, tmax);
+    };
     {
         double tmin, tmax;
-        slab_finite(ray.o, inv, tree.root_box[0], tree.root_box[1], tree.root_box[2], tree.root_box[3], tree.root_box[4], tree.root_box[5], tmin, tmax);
+        slab(tree.root_box, tmin, tmax);
         if (tmax < 0.0f || tmin > tmax || tmin > cut) return best;
     }
     auto visit_leaf = [&](int primitive) {
@@ -292,7 +300,10 @@ PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Lea
         }
     };
     if (tree.root < 0) {
-        visit_leaf(~tree.root);
+        // one primitive, no inner node: the reference returns the leaf's own result, with no comparison in which a hit at
+        // an infinite distance (a sphere whose r * r overflows) would lose to a miss (src/path_tracing.cpp:113-127)
+        double d;
+        if (leaf.test(ray, ~tree.root, d)) best = Hit{~tree.root, d};
         return best;
     }
     int sp = 0;
@@ -301,8 +312,8 @@ PT_DEV Hit closest_pruned(const Ray& ray, D3 inv, const TreeRef& tree, const Lea
         const PairNode* p = tree.pairs + cur;
         const int lref = p->left, rref = p->right;
         double lmin, lmax, rmin, rmax;
-        slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
-        slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
+        slab(p->lbox, lmin, lmax);
+        slab(p->rbox, rmin, rmax);
         bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
         bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
         if (go_l && lref < 0) { visit_leaf(~lref); go_l = false; }
@@ -341,7 +352,8 @@ PT_DEV TourFrame* wave_frames(BlockShared& sh) { return sh.frames + (threadIdx.x
 enum RayClass { RAY_FINITE = 0, RAY_EXACT_ONLY = 1, RAY_POISONED = 2 };
 PT_DEV int classify_ray(const Ray& ray, D3 inv) {
     if (any_nan(ray.o) || any_nan(ray.d)) return RAY_POISONED;
-    return (isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z)) ? RAY_FINITE : RAY_EXACT_ONLY;
+    // an infinite origin makes `plane - origin` infinite or NaN: exact traversal as well
+    return (isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z) && isfinite(ray.o.x) && isfinite(ray.o.y) && isfinite(ray.o.z)) ? RAY_FINITE : RAY_EXACT_ONLY;
 }
 
 // Closest hit in one tree with the reference's semantics (whole search by the calling lane).
@@ -377,7 +389,10 @@ PT_DEV bool shade_vertex(const DeviceScene& s, Ray& ray, const Hit& hs, const Hi
     if (hs.index != -1 || ht.index != -1) {
         D3 p, n;
         int material_index;
-        if (hs.distance < ht.distance) {                                   // :183-194
+        // A sphere can be "hit" at an infinite distance (r * r overflows from |r| = 1.4e154 on) while every triangle is
+        // missed: the comparison of :183 then sends the reference to triangle -1, where its assert stops it (:196).
+        // Here such a vertex is the sphere's: the one index that exists.  Nothing else is changed by the second clause.
+        if (hs.distance < ht.distance || ht.index == -1) {                 // :183-194
             const double* sp = s.spheres + 4 * hs.index;
             p = add3(ray.o, scale3(hs.distance, ray.d));
             const double sign = (sp[3] < 0.0f) ? -1.0f : 1.0f;

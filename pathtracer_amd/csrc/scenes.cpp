@@ -48,6 +48,7 @@ int finish(PtHostScene* scene) {
     if (!scene->spheres.empty()) {
         std::vector<PtAabb> boxes;
         for (const PtSphere& s : scene->spheres) boxes.push_back(box_of(s));
+        if (!sortable(boxes)) return fail(PT_ERR_INVALID_ARGUMENT, "a sphere has a NaN centre or radius: no BVH can be built");
         scene->sphere_bvh.resize(2 * boxes.size() - 1);
         build_bvh(boxes, scene->sphere_bvh.data(), threads);
     }
@@ -57,6 +58,7 @@ int finish(PtHostScene* scene) {
         in_parts(0, static_cast<long long>(boxes.size()), boxes.size() >= (1u << 16) ? host_threads() : 1, [&](long long from, long long to, int) {
             for (long long i = from; i < to; ++i) boxes[i] = box_of(scene->triangles[i]);
         });
+        if (!sortable(boxes)) return fail(PT_ERR_INVALID_ARGUMENT, "a triangle has a NaN coordinate: no BVH can be built");
         clock.done("triangle boxes");
         scene->triangle_bvh.resize(2 * boxes.size() - 1);
         clock.done("node array allocated");
