@@ -203,6 +203,12 @@ def test_random_scenes_against_the_checker(api, orc, seed):
             spheres[rng.integers(0, len(spheres)), rng.integers(0, 4)] = rng.choice(odd)
     arrays = _scene(api, triangles, spheres, tri_materials=rng.integers(0, 4, len(triangles)),
                     sph_materials=None if spheres is None else rng.integers(0, 4, len(spheres)))
+    if seed % 7 == 6:                                                                  # any numbers as material parameters
+        values = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1.5, 2.0, 1e-300, 1e300, np.inf, -np.inf, np.nan, 0.999, 1.0000001, 7.0])
+        materials = arrays["materials"].copy()
+        for m in materials:
+            m["v"] = np.where(rng.random(4) < 0.5, rng.choice(values, 4), rng.uniform(-0.2, 1.6, 4))
+        arrays["materials"] = materials
     eye = tuple(rng.uniform(-4, 4, 3)) if seed % 5 == 0 else tuple(rng.uniform(12, 25, 3) * rng.choice([-1, 1], 3))
     size = (int(rng.integers(9, 70)), int(rng.integers(9, 50)))
     _compare(api, orc, arrays, eye, (0.0, 0.0, 0.0), size=size, spp=int(rng.integers(1, 4)), bounces=int(rng.choice([1, 4, 12, 50])),
@@ -234,6 +240,15 @@ def test_random_frames_against_the_checker(api, orc, seed):
     frame = api.camera_frame(cam, width / height, width, height, row_begin=rows[0], row_end=rows[1],
                              sample_begin=int(rng.integers(0, 40)), sample_count=int(rng.choice([1, 5, 16, 17, 33, 50])),
                              max_bounces=int(rng.choice([0, 1, 3, 12, 50])), shard_count=shards, shard_index=int(rng.integers(0, shards)))
+    if seed % 13 == 4:                                   # any numbers in the camera: the rays may be NaN, infinite, parallel to an axis
+        values = np.array([0.0, -0.0, 1.0, -1.0, 1e-300, 1e160, 1e300, -1e300, np.inf, -np.inf, np.nan])
+        for name in ("camera_position", "camera_x", "camera_y", "bottom_left", "step_x", "step_y"):
+            vector = getattr(frame, name)
+            for axis in "xyz":
+                if rng.random() < 0.25:
+                    setattr(vector, axis, float(rng.choice(values)))
+        if rng.random() < 0.5:
+            frame.aperture = float(rng.choice([-1.0, 0.0, 1e300, np.inf, np.nan, 3.0]))
     held = rng.uniform(0, 3, 4 * width * height)
     saved = {k: os.environ.pop(k, None) for k in ("PT_WORKSPACE_GB", "PT_KERNEL")}
     try:
@@ -248,3 +263,31 @@ def test_random_frames_against_the_checker(api, orc, seed):
             if v is not None:
                 os.environ[k] = v
     assert same_bits(got, checker.render(frame, held.copy(), threads=4))
+
+
+def test_corrupted_trees_are_refused_or_followed(api, orc):
+    """A caller's tree with one field overwritten: pt_scene_create either refuses it (an index the reference would follow out of
+    its arrays, a node reached twice, a primitive named twice or never) or, if it is still a tree over every primitive, renders
+    what the reference's traversal of those very nodes gives."""
+    from oracle.bindings import make_desc
+    rng = np.random.default_rng(404)
+    triangles = (rng.uniform(-6, 6, (90, 1, 3)) + rng.normal(0, 1.0, (90, 3, 3))).reshape(-1, 9)
+    arrays = _scene(api, triangles, tri_materials=rng.integers(0, 4, 90))
+    refused = followed = 0
+    for trial in range(60):
+        nodes = arrays["triangle_bvh"].copy()
+        i = int(rng.integers(0, len(nodes)))
+        field = ("left", "right", "index")[trial % 3]
+        nodes[field][i] = int(rng.choice([-1, 0, 1, i, len(nodes), len(nodes) + 7, 2 ** 31 - 1, -2 ** 31, int(rng.integers(0, len(nodes)))]))
+        broken = dict(arrays)
+        broken["triangle_bvh"] = nodes
+        desc, keep = make_desc(broken)
+        try:
+            api.DeviceScene(desc, keepalive=keep)
+        except api.PathTracerError as e:
+            assert e.code == abi.PT_ERR_INVALID_ARGUMENT, e
+            refused += 1
+            continue
+        _compare(api, orc, broken, (2.0, 3.0, 20.0), (0.0, 0.0, 0.0), size=(40, 28), spp=1, bounces=4, own_trees=False)
+        followed += 1
+    assert refused > 20 and followed > 0, (refused, followed)
