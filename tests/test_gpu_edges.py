@@ -195,6 +195,9 @@ def test_random_scenes_against_the_checker(api, orc, seed):
         spheres = np.concatenate([rng.uniform(-8, 8, (n, 3)), rng.uniform(0.3, 2.5, (n, 1))], 1)
         if seed % 4 == 3:
             spheres[::2, 3] *= -1.0                                                    # hollow: inverted boxes
+        if seed % 6 == 3 and seed >= 16:
+            spheres = np.concatenate([rng.integers(-6, 7, (n, 3)), rng.integers(1, 3, (n, 1))], 1).astype(float)   # on the triangles' lattice
+            spheres = np.concatenate([spheres, spheres[: max(1, n // 3)]])                                         # and duplicated: tied spheres
     if seed % 11 == 5:                                                                 # unbounded and huge coordinates
         odd = np.array([np.inf, -np.inf, 1e300, -1e300, 1e160, 3e6])
         hit = rng.random(triangles.shape) < 0.01
@@ -210,6 +213,8 @@ def test_random_scenes_against_the_checker(api, orc, seed):
             m["v"] = np.where(rng.random(4) < 0.5, rng.choice(values, 4), rng.uniform(-0.2, 1.6, 4))
         arrays["materials"] = materials
     eye = tuple(rng.uniform(-4, 4, 3)) if seed % 5 == 0 else tuple(rng.uniform(12, 25, 3) * rng.choice([-1, 1], 3))
+    if seed % 12 == 9:
+        eye = tuple(float(v) for v in rng.integers(8, 20, 3) * rng.choice([-1, 1], 3))   # a lattice point: with aperture 0 every ray starts there
     size = (int(rng.integers(9, 70)), int(rng.integers(9, 50)))
     _compare(api, orc, arrays, eye, (0.0, 0.0, 0.0), size=size, spp=int(rng.integers(1, 4)), bounces=int(rng.choice([1, 4, 12, 50])),
              aperture=float(rng.choice([0.0, 0.05, 0.6])))
