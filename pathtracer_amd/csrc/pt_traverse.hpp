@@ -350,6 +350,12 @@ PT_DEV TourFrame* wave_frames(BlockShared& sh) { return sh.frames + (threadIdx.x
 // miss.  An infinite reciprocal can make slab products NaN, where the exact min/max order
 // of the reference matters: such rays go through the exact traversal.
 enum RayClass { RAY_FINITE = 0, RAY_EXACT_ONLY = 1, RAY_POISONED = 2 };
+// The same for a caller that goes on to demand |origin| <= 2^20 of a RAY_FINITE ray (ray32_allowed): the origin's
+// finiteness is then implied and not tested twice.
+PT_DEV int classify_ray_of_bounded_origin(const Ray& ray, D3 inv) {
+    if (any_nan(ray.o) || any_nan(ray.d)) return RAY_POISONED;
+    return (isfinite(inv.x) && isfinite(inv.y) && isfinite(inv.z)) ? RAY_FINITE : RAY_EXACT_ONLY;
+}
 PT_DEV int classify_ray(const Ray& ray, D3 inv) {
     if (any_nan(ray.o) || any_nan(ray.d)) return RAY_POISONED;
     // an infinite origin makes `plane - origin` infinite or NaN: exact traversal as well

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             if (st == ST_NEWRAY) {
                 inv = D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
                 constexpr bool merged = NODE32 && MERGED;
-                int kind = classify_ray(ray, inv);
+                int kind = NODE32 ? classify_ray_of_bounded_origin(ray, inv) : classify_ray(ray, inv);
                 if (NODE32 && kind == RAY_FINITE && !ray32_allowed(ray, inv)) kind = RAY_EXACT_ONLY;
                 hs = Hit{-1, REAL_MAX};
                 if (s.sph_tree.count == 1) {
@@ -367,10 +367,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     double tmin, tmax, d;
                     box_test(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
                     if (!(tmax < 0.0f || tmin > tmax) && hit_sphere(ray, s.spheres, d)) hs = Hit{0, d};
-                } else if (!merged || kind != RAY_FINITE) {
-                    // spheres outside the search hierarchy, or a ray the hierarchy cannot take: the lane walks
-                    // the sphere tree on its own
+                } else if (!merged) {
+                    // spheres outside the search hierarchy: the lane walks the sphere tree on its own
                     hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, stack_ref, frames);
+                } else if (__ballot(kind == RAY_EXACT_ONLY) != 0ull) {
+                    // a ray the hierarchy cannot take: the reference's own traversal of the sphere tree (a ray with a NaN
+                    // hits nothing, src/geometry.cpp:59-82)
+                    resolve_slow_lanes(kind == RAY_EXACT_ONLY, ray, s.sph_tree, sph_leaf, frames, hs);
                 }
                 best_i = -1;
                 best_t = REAL_MAX;
