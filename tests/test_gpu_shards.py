@@ -194,3 +194,37 @@ def test_benchmark_frame_at_256_samples_against_the_checker(scenes):
     for row in (3, 540, 1072):
         expect = checker.render(host.frame(w, h, sample_count=spp, row_begin=row, row_end=row + 1), threads=16)
         assert same_bits(image[row].cpu().numpy(), expect.reshape(h, w, 4)[row])
+
+
+def test_two_host_threads_render_through_two_handles_at_once(api, orc):
+    """Distinct handles are independent: two host threads, each with a scene handle and a stream of its own, create their scenes
+    and render different frames at the same time (ctypes drops the interpreter lock during the calls); each gets the bytes a
+    lone render gives."""
+    import threading
+    import torch
+    host = api.HostScene(abi.PT_SCENE_CHESS32, MODELS)
+    frames = [host.frame(320, 200, sample_count=24), host.frame(256, 144, sample_count=40, max_bounces=12)]
+    checker = orc.scene_create(host.arrays())
+    expect = [checker.render(f, threads=8).reshape(f.height, f.width, 4) for f in frames]
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            device = api.DeviceScene.from_host(host)
+            stream = torch.cuda.Stream()
+            for _ in range(3):                       # several launches each, so that they do overlap
+                buf = torch.zeros((frames[i].height, frames[i].width, 4), dtype=torch.float64, device="cuda:0")
+                device.render_device(frames[i], buf.data_ptr(), stream.cuda_stream)
+                stream.synchronize()
+            results[i] = buf.cpu().numpy()
+        except Exception as e:                       # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        assert same_bits(results[i], expect[i])
