@@ -207,8 +207,9 @@ PT_DEV double prune_cut(double limit) { return limit + (1.0e-7 * fabs(limit) + 1
 // One lane of a wave runs this at a time, with its frames in that wave's LDS slice.
 struct TourFrame { int right; int state; int left_index; double left_distance; };
 
+// Arguments by value: they travel in registers, so that no caller has to keep its ray in memory for this call's sake.
 template <class Leaf>
-__device__ __noinline__ Hit tournament(const Ray& ray, const TreeRef& tree, const Leaf& leaf, TourFrame* frames) {
+__device__ __noinline__ Hit tournament(const Ray ray, const TreeRef tree, const Leaf leaf, TourFrame* frames) {
     const D3 inv{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
     Hit result{-1, REAL_MAX};
     int depth = 0;
