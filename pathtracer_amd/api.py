@@ -287,11 +287,7 @@ class DeviceScene:
         check(lib().pt_last_render_stats(self.handle, ptr(out)))
         names = ["node_phases", "node_lanes", "leaf_phases", "leaf_lanes", "shade_phases", "shade_lanes", "loops", "paths",
                  "unsafe_skips", "t_node", "t_leaf", "t_shade", "t_refill", "t_setup", "t_total"]
-        st = dict(zip(names, out.tolist()))
-        if st["t_total"] == 0:       # the counting build takes no clocks: their first two slots hold the stack's spill counters
-            st["spills"], st["abandoned"] = st["t_node"], st["t_leaf"]
-            st["t_node"] = st["t_leaf"] = 0
-        return st
+        return dict(zip(names, out.tolist()))
 
     def primary_hits(self, frame):
         tri = np.full((frame.height, frame.width), -2, np.int32)

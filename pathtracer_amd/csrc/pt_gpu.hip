@@ -217,8 +217,7 @@ __global__ void eval_kernel(int op, const void* __restrict__ in, long long n, vo
 // only a handle for hipGetSymbolAddress: kernels, memsets and copies are given the address that call returns.
 constexpr size_t STATIC_COUNTER_BYTES = 1024;
 constexpr size_t STATIC_COLOUR_BYTES = size_t(PT_NOALLOC_MAX_TILES) * 4 * CHUNK_PATHS * sizeof(double);   // one sample group of that many tiles
-constexpr size_t STATIC_SPILL_BYTES = size_t(32) << 20;     // backing store of the lanes' stacks (behind the colour records)
-static __device__ __align__(256) unsigned char scratch[STATIC_COUNTER_BYTES + STATIC_COLOUR_BYTES + STATIC_SPILL_BYTES];
+static __device__ __align__(256) unsigned char scratch[STATIC_COUNTER_BYTES + STATIC_COLOUR_BYTES];
 
 namespace {
 
@@ -411,8 +410,8 @@ struct PtScene {
     hipStream_t last_stream = nullptr;
     bool timed = false;
     // wavefront kernel: per-path colours, the chunk counter and the profiling counters
-    DeviceBuffer rgb, counters, spill;
-    size_t rgb_bytes = 0, spill_bytes = 0;
+    DeviceBuffer rgb, counters;
+    size_t rgb_bytes = 0;
     void* last_counters = nullptr;      // counters of the most recent wavefront launch (the scene's own or the static workspace's)
     void* static_workspace = nullptr;   // this device's copy of the static workspace (pt_render_device_noalloc)
     bool albedo_bounded = false;        // every albedo finite with |albedo| <= 1
@@ -649,14 +648,12 @@ struct Tunables {
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
     int shade_threshold = 36;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams (swept: profiles/r2/threshold_sweep.log)
     int leaf_threshold = 20;
-    int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search in LDS (0 = the default window)
-    bool stack_spill = true;            // PT_STACK_SPILL=0: no backing store (a lane that outgrows its slots takes the exhaustive traversal)
+    int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
     int distrust_mask = -1;             // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winner to the fallback)
     Tunables() {
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
         if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
         if (const char* v = std::getenv("PT_STACK_SLOTS")) stack_slots = std::atoi(v);
-        if (const char* v = std::getenv("PT_STACK_SPILL")) stack_spill = std::atoi(v) != 0;
         if (const char* v = std::getenv("PT_DISTRUST_MASK")) distrust_mask = std::atoi(v);
         if (const char* v = std::getenv("PT_SHADE_THRESHOLD")) shade_threshold = std::max(1, std::atoi(v));
         if (const char* v = std::getenv("PT_LEAF_THRESHOLD")) leaf_threshold = std::max(1, std::atoi(v));
@@ -681,7 +678,6 @@ struct TraceOutputs {
     unsigned long long* stats = nullptr;
     int* hit_triangle = nullptr;     // both null unless the launch reports first-vertex indices
     int* hit_sphere = nullptr;
-    int* spill = nullptr;            // backing store of the lanes' stacks; null unless WorkParams::spill_slots > 0
 };
 
 template <int STATS, bool NODE32, bool MERGED>
@@ -693,7 +689,7 @@ int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, 
         return PT_OK;
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream,
-                       TraceArgs{dev, fp, wp, out.rgb, out.counter, out.stats, out.hit_triangle, out.hit_sphere, out.spill});
+                       TraceArgs{dev, fp, wp, out.rgb, out.counter, out.stats, out.hit_triangle, out.hit_sphere});
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -724,8 +720,6 @@ struct Workspace {
     bool fixed = false;
     int* hit_triangle = nullptr;   // set by pt_primary_hits: the launch reports the first-vertex indices of both traversals
     int* hit_sphere = nullptr;
-    int* spill = nullptr;          // backing store of the lanes' stacks (fixed workspaces bring their own)
-    size_t spill_bytes = 0;
 };
 
 // The scene's own workspace, grown to `want` bytes of colour records if the device has them, else to what it
@@ -777,20 +771,12 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     // per-lane stack slots: the triangle search's need, and the sphere tree's when it is walked in place
     // (a lane of the 4-wide search that would outgrow its slots falls back to the exhaustive traversal, so
     // any number >= 3 is correct there; the binary search and the sphere tree need their full height)
-    // The 4-wide search keeps a window of its stack in LDS and the rest in a backing store (pt_wavefront.hpp, ST_SPILL);
-    // without a store, a lane that outgrows the window falls back to the exhaustive traversal, so any window >= 4 is correct.
-    const int window = t.stack_slots > 0 ? std::max(t.stack_slots, t.stack_spill ? 2 * SPILL_STEP : 4) : DEFAULT_STACK_WINDOW;
-    const int quad_slots = std::max(4, std::min(window, scene->tri_stack_need));
+    const int quad_slots = std::max(4, t.stack_slots > 0 ? std::min(t.stack_slots, scene->tri_stack_need) : scene->tri_stack_need);
     const int stack_slots = std::min(std::max(std::max(node32 ? quad_slots : scene->tri_height, scene->sph_height), 4),
                                      static_cast<int>(MAX_WF_STACK_SLOTS));
-    int spill_slots = 0;
-    if (node32 && t.stack_spill && scene->tri_stack_need > stack_slots) {
-        spill_slots = (scene->tri_stack_need - stack_slots + SPILL_STEP - 1) / SPILL_STEP * SPILL_STEP + SPILL_STEP;
-    }
     const size_t stack_bytes = static_cast<size_t>(stack_slots) * BLOCK_THREADS * sizeof(int);
     const int variant = 4 * stack_slots + 2 * (t.stats & 1) + (node32 ? 1 : 0) + 1024 * (t.stats >> 1);
-    const bool occupancy_unknown = scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0;
-    if (occupancy_unknown) {
+    if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, scene->device));
         scene->compute_units = prop.multiProcessorCount;
@@ -799,23 +785,6 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         const int rc = trace_paths(t.stats, node32, 0, stack_bytes, stream, scene->dev, FrameParams{}, WorkParams{}, TraceOutputs{}, &per_cu);
         if (rc != PT_OK) return rc;
         scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
-    }
-    // the stacks' backing store: one region per wave the grid can hold
-    const size_t grid_waves = static_cast<size_t>(scene->compute_units) * scene->blocks_per_cu * (BLOCK_THREADS / 64);
-    if (spill_slots > 0) {
-        const size_t bytes_per_slot = grid_waves * 64 * sizeof(int);
-        if (!ws.fixed) {
-            const size_t want = bytes_per_slot * spill_slots;
-            if (scene->spill_bytes < want) {
-                if (scene->spill.p != nullptr) { HIP_TRY(hipFree(scene->spill.p)); scene->spill.p = nullptr; scene->spill_bytes = 0; }
-                HIP_TRY(hipMalloc(&scene->spill.p, want));
-                scene->spill_bytes = want;
-            }
-            ws.spill = static_cast<int*>(scene->spill.p);
-            ws.spill_bytes = scene->spill_bytes;
-        }
-        // a store too small for the deepest search only means that such a search is given up (exhaustive traversal instead)
-        spill_slots = static_cast<int>(std::min<size_t>(spill_slots, ws.spill_bytes / bytes_per_slot / SPILL_STEP * SPILL_STEP));
     }
     unsigned int* counter = static_cast<unsigned int*>(ws.counters);
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws.counters) + 512);
@@ -838,7 +807,6 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.shade_threshold = t.shade_threshold;
         wp.leaf_threshold = t.leaf_threshold;
         wp.stack_slots = stack_slots;
-        wp.spill_slots = spill_slots;
         wp.distrust_mask = t.distrust_mask;
         wp.export_hits = ws.hit_triangle != nullptr ? 1 : 0;
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
@@ -846,7 +814,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
                                                                           (units + 3) / 4));
         const int rc = trace_paths(t.stats, node32, blocks, stack_bytes, stream, scene->dev, fp, wp,
-                                   TraceOutputs{ws.rgb, counter, stats, ws.hit_triangle, ws.hit_sphere, spill_slots > 0 ? ws.spill : nullptr}, nullptr);
+                                   TraceOutputs{ws.rgb, counter, stats, ws.hit_triangle, ws.hit_sphere}, nullptr);
         if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,
                            fp, wp, static_cast<const double*>(ws.rgb), accum_device);
@@ -1054,8 +1022,6 @@ int pt_render_device_noalloc(PtScene* scene, const PtFrame* frame, double* accum
     ws.counters = base;
     ws.rgb = reinterpret_cast<double*>(base + STATIC_COUNTER_BYTES);
     ws.rgb_bytes = STATIC_COLOUR_BYTES;
-    ws.spill = reinterpret_cast<int*>(base + STATIC_COUNTER_BYTES + STATIC_COLOUR_BYTES);
-    ws.spill_bytes = STATIC_SPILL_BYTES;
     ws.fixed = true;
     return launch_render(scene, frame, accum_device, static_cast<hipStream_t>(hip_stream), ws);
 }

@@ -33,10 +33,6 @@ constexpr int SAMPLES_PER_CHUNK = PT_SAMPLES_PER_CHUNK;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
 constexpr int MAX_SEARCH_HEIGHT = 32;  // levels the rebuilt binary hierarchy is kept to (= STACK_DEPTH: a height cap near the minimum forces balanced splits and costs large scenes a third of their speed)
 constexpr int MAX_WF_STACK_SLOTS = 36; // per-lane stack slots a block is given at most (1 KB of LDS each): three blocks per CU still fit
-#ifndef PT_STACK_WINDOW
-#define PT_STACK_WINDOW 24
-#endif
-constexpr int DEFAULT_STACK_WINDOW = PT_STACK_WINDOW;   // slots of the 4-wide search's stack kept in LDS; deeper entries go to the backing store
 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
@@ -46,7 +42,6 @@ struct WorkParams {
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
-    int spill_slots;             // per-lane entries of the stack's backing store in device memory (a multiple of SPILL_STEP; 0 = none)
     int distrust_mask;           // test aid: a winner whose index has none of these bits set is sent to the exhaustive
                                  // traversal as if its box test had failed (negative = never)
     int export_hits;             // the launch reports each path's first-vertex triangle and sphere index (TraceArgs::hit_*):
@@ -71,7 +66,6 @@ struct TraceArgs {
     unsigned long long* stats;
     int* hit_triangle;           // per pixel (row * width + column), written at a path's first vertex; null unless w.export_hits
     int* hit_sphere;
-    int* spill;                  // backing store of the lanes' stacks: [wave of the grid][entry][lane]; null unless w.spill_slots > 0
 };
 // The argument struct behind a pointer the compiler must treat as new at this point: what is read through
 // it is fetched here, by scalar loads, instead of being kept in scalar registers across the whole work
@@ -83,17 +77,11 @@ PT_DEV ArgsInMemory args_fetched_here() {
     return p;
 }
 
-enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4, ST_SPILL = 5 };
-// The lanes' stacks live in LDS, which is what limits the waves per CU, so a lane is given fewer slots than the deepest
-// search can need.  A lane about to outgrow them (ST_SPILL) moves its SPILL_STEP oldest entries to a backing store in
-// device memory and goes on; a lane that has used up its slots while entries lie there takes the youngest SPILL_STEP
-// back.  Both happen in the shade branch of the work loop, so the node and leaf steps carry no code for them.
-constexpr int SPILL_STEP = 8;
+enum LaneState { ST_NEED = 0, ST_LEAF = 1, ST_SHADE = 2, ST_NEWRAY = 3, ST_NODE = 4 };
 
 struct WaveStats {   // wave-uniform counters of a profiling build
     unsigned long long node_phases, node_lanes, leaf_phases, leaf_lanes, shade_phases, shade_lanes, loops, paths;
     unsigned long long unsafe_skips;   // f32 test skipped a box the exact test accepts: must stay 0
-    unsigned long long spills, abandoned;   // stack entries moved out to device memory (in steps); searches given up for want of room there
     unsigned long long t_node, t_leaf, t_shade, t_refill, t_setup, t_total;   // shader-clock ticks spent per section
 };
 
@@ -133,14 +121,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
     bool work_left = true;          // units may remain on the counter
     long long pool_first = 0;       // colour-scratch slot of the pool's first path
     int pool_taken = 64;            // entries of the pool below this are gone
-    WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    WaveStats ws{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = (STATS == 2) ? clock64() : 0;
     long long t0 = 0;
 
     // per-lane path state
     int st = ST_NEED;
     int cur = 0, sp = 0, bounce = 0, best_i = -1;
-    int spilled = 0;                    // entries of the lane's stack that lie in the backing store, below those in LDS
     long long slot = 0;                 // place of the lane's path in the colour scratch: unit * 64 + pixel of the tile
     bool tie = false, tie_s = false;    // a second triangle / sphere at exactly the best triangle / sphere distance
     double best_t = REAL_MAX, cut = REAL_MAX;
@@ -212,9 +199,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
         // waves per CU).  A lane whose next visit could outgrow its stack gives up the ordered search
         // and is resolved like a tie, by the exhaustive traversal, when it is shaded.
-        // With a backing store the lane makes room first (ST_SPILL); `cur` and the entries below `top` are what it resumes with.
         const bool overflow = sp + 3 > w.stack_slots;
-        st = overflow ? ST_SPILL : ((sp == 0) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE));
+        tie = tie | overflow;
+        st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
         sp = top;
         cur = next;
     };
@@ -224,7 +211,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
         const bool paths_left = work_left || pool_taken < 64;
         // no lane is in ST_NEWRAY here (the set-up below resolves it at once): whoever is in none of the three is idle
-        const unsigned long long m_shade = __ballot(st == ST_SHADE || st == ST_SPILL);
+        const unsigned long long m_shade = __ballot(st == ST_SHADE);
         const unsigned long long m_ready = paths_left ? ~(m_node | m_leaf) : m_shade;
         const int n_ready = __popcll(m_ready);
         if (STATS) ++ws.loops;
@@ -236,35 +223,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             const ArgsInMemory fetched = args_fetched_here();
             const FrameParams& f = *(const FrameParams*)&fetched->f;      // camera and frame: used by this branch only
             const DeviceScene& scene_for_shading = *(const DeviceScene*)&fetched->s;   // materials, normals, background
-            // ---------------- stacks that have outgrown their slots in LDS, or used them up while older entries lie outside
-            if (NODE32) {
-                const bool out = st == ST_SPILL, in = (st == ST_SHADE) & (spilled > 0);
-                if (__ballot(out | in) != 0ull) {
-                    const int spill_slots = fetched->w.spill_slots;      // 0 without a backing store: whoever outgrows his slots gives up
-                    const bool room = spilled + SPILL_STEP <= spill_slots;
-                    if (STATS) { ws.spills += __popcll(__ballot(out & room)); ws.abandoned += __popcll(__ballot(out & !room)); }
-                    int* const backing = fetched->spill + (size_t)(blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6)) * (size_t)(spill_slots * 64) + lane;
-                    if (out & !room) {
-                        // no room there either: the ordered search is given up and the exhaustive traversal answers
-                        tie = true;
-                        spilled = 0;
-                        sp = 0;
-                        st = ST_SHADE;
-                    } else if (out) {
-                        for (int i = 0; i < SPILL_STEP; ++i) backing[(spilled + i) * 64] = stack_ref[i * BLOCK_THREADS];
-                        for (int i = SPILL_STEP; i < sp; ++i) stack_ref[(i - SPILL_STEP) * BLOCK_THREADS] = stack_ref[i * BLOCK_THREADS];
-                        spilled += SPILL_STEP;
-                        sp -= SPILL_STEP;
-                        st = (cur < 0) ? ST_LEAF : ST_NODE;
-                    } else if (in) {
-                        for (int i = 0; i < SPILL_STEP; ++i) stack_ref[i * BLOCK_THREADS] = backing[(spilled - SPILL_STEP + i) * 64];
-                        spilled -= SPILL_STEP;
-                        cur = stack_ref[(SPILL_STEP - 1) * BLOCK_THREADS];
-                        sp = SPILL_STEP - 1;
-                        st = (cur < 0) ? ST_LEAF : ST_NODE;
-                    }
-                }
-            }
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
@@ -422,7 +380,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                 tie = false;
                 tie_s = false;
                 sp = 0;
-                spilled = 0;
                 st = ST_SHADE;                       // unless a search is started below
                 if (kind == RAY_EXACT_ONLY && s.tri_tree.count > 0) {
                     Hit ht{-1, REAL_MAX};
@@ -543,7 +500,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         atomicAdd(stats + 4, ws.shade_phases); atomicAdd(stats + 5, ws.shade_lanes);
         atomicAdd(stats + 6, ws.loops); atomicAdd(stats + 7, ws.paths);
         atomicAdd(stats + 8, ws.unsafe_skips);
-        if (STATS == 1) { atomicAdd(stats + 9, ws.spills); atomicAdd(stats + 10, ws.abandoned); }   // the slots of the section clocks, which this build does not take
     }
 }
 
