@@ -10,13 +10,17 @@ A step = one full frame: zero the f64 BGRA+count buffer, render every pixel's 25
 triangles, materials) is resident in each GPU's HBM before the timed region.  Rank 0 prints one
 JSON line.  Msamples/s = width * height * spp * steps / seconds / 1e6, whole job.
 
-What the line's `roofline` is.  The dominant kernel (trace_paths_kernel) is priced against the two
-resources north_star names, both from work the kernel EXECUTES:
+What the line's `roofline` is.  The dominant kernel (trace_paths_kernel) is priced against the resources it
+can run out of, each from work the kernel EXECUTES:
   valu  wave-wide vector instructions issued (committed rocprofv3 count per path, profiles/executed_work.json)
         x 64 lanes x paths of the launch / live kernel time, against SIMDs x 16 lanes x clock;
+  l1    accesses of the vector L1 (committed TCP_TOTAL_CACHE_ACCESSES per path: a 16-byte load by lanes that
+        each stand on their own node or triangle costs one per lane) x paths / live kernel time, against one
+        access per compute unit per cycle (measured: profiles/r2/micro_l1_gather.txt, profiles/r3/micro_l1_pieces.txt);
   hbm   memory-side bytes of the launch (committed FETCH_SIZE/WRITE_SIZE passes, profiles/hbm_traffic.json)
         / live kernel time, against the 8 TB/s HBM peak.
-The primary `roofline` is whichever of the two is nearer its peak (the binding one); both are given.  The
+The primary `roofline` is whichever of them is nearest its peak (the binding one); all are given, with
+`occupancy` (waves per SIMD of the 8 the hardware holds, from the library's own occupancy query).  The
 reference's exhaustive traversal would touch far more bytes per sample than this kernel's pruned search;
 that figure is reported apart, as `algorithmic`, and is no fraction of any peak.
 """
@@ -40,6 +44,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E, spec
 CLOCK_GHZ = 2.4                 # max engine clock
 LANES_PER_SIMD = 16             # a 64-wide vector instruction occupies its SIMD for 4 cycles
 SIMDS_PER_CU = 4
+L1_ACCESSES_PER_CU_PER_CYCLE = 1.0      # lanes that each read 16 bytes of their own line: measured, profiles/r3/micro_l1_pieces.txt
+WAVES_PER_SIMD_MAX = 8
 SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
           "grid": abi.PT_SCENE_CHESS_GRID, "spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}
 # bytes the kernel asks the memory hierarchy for, per executed step (what it reads of each record)
@@ -204,15 +210,28 @@ def main():
     accum = torch.zeros((h, w, 4), dtype=torch.float64, device=device)
     stream = torch.cuda.current_stream(device).cuda_stream
 
-    def step():
+    # the gather's buffers are made before the timed region (gather_rows keeps them per frame size); the rehearsal
+    # backend gathers through a pinned host copy
+    staging = torch.empty((h, w, 4), dtype=torch.float64, pin_memory=True) if (world > 1 and backend != "nccl") else None
+    gather_events = []
+
+    def step(timed=False):
         accum.zero_()
         scene.render_device(frame, accum.data_ptr(), stream)
-        if backend == "nccl" or world == 1:
+        if world == 1:
+            return
+        before, after = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        before.record()
+        if backend == "nccl":
             gather_rows(accum, h, w, rank, world)
         else:
-            staged = gather_rows(accum.cpu(), h, w, rank, world)
+            staging.copy_(accum)
+            gather_rows(staging, h, w, rank, world)
             if rank == 0:
-                accum.copy_(staged)
+                accum.copy_(staging)
+        after.record()
+        if timed:
+            gather_events.append((before, after))
 
     def fence():
         if world > 1:
@@ -225,7 +244,7 @@ def main():
     kernel_ms = []
     start = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
         kernel_ms.append(scene.last_render_ms())   # HIP events around the kernels on their launch stream
     fence()
     seconds = time.perf_counter() - start
@@ -233,6 +252,15 @@ def main():
         t = torch.tensor([seconds], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seconds = float(t.item())
+    # every rank's own kernel time and gather time (means over the timed steps), for rank 0 to report: what the slowest
+    # rank adds is load imbalance, what the gather adds is the exchange
+    per_rank = None
+    if world > 1:
+        gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0
+        mine = torch.tensor([float(np.mean(kernel_ms)), gather_ms], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = {"kernel_ms": [float(v[0]) for v in everyone], "gather_ms": [float(v[1]) for v in everyone]}
 
     if rank == 0:
         samples_per_step = w * h * args.spp
@@ -246,7 +274,17 @@ def main():
         per_path, _, work_from = table("executed_work.json", workload)      # committed rocprofv3 instruction counts of this workload
         traffic, traffic_paths, traffic_from = table("hbm_traffic.json", workload)
         hbm_bytes = None if traffic is None else traffic["trace_paths_kernel"]["hbm_bytes_per_launch"] / traffic_paths * launch_paths
-        valu = hbm = None
+        blocks_per_cu = scene.last_launch_shape()[0]
+        occupancy = {"waves_per_simd": blocks_per_cu, "of": WAVES_PER_SIMD_MAX, "frac": blocks_per_cu / WAVES_PER_SIMD_MAX,
+                     "basis": "persistent blocks of 256 threads per compute unit = waves per SIMD (hipOccupancyMaxActiveBlocksPerMultiprocessor of the "
+                              "kernel with its LDS stacks, made by the library before the launch); registers allow 3, LDS 3"}
+        valu = hbm = l1 = None
+        if per_path is not None and per_path.get("l1_accesses_per_path"):
+            l1_peak = compute_units * CLOCK_GHZ * L1_ACCESSES_PER_CU_PER_CYCLE              # G accesses / s
+            rate = per_path["l1_accesses_per_path"] * launch_paths / launch_s / 1e9
+            l1 = {"bound": "l1", "achieved": rate, "peak": l1_peak, "unit": "Gaccess/s", "frac": rate / l1_peak,
+                  "basis": f"{per_path['l1_accesses_per_path']:.1f} vector-L1 accesses per path (TCP_TOTAL_CACHE_ACCESSES, {per_path['source']}) x paths "
+                           "/ live kernel time; peak = CUs x 2.4 GHz x one access per cycle (a 16-byte load by lanes on lines of their own: measured)"}
         if per_path is not None:
             tops = per_path["valu_wave_instructions_per_path"] * 64 * launch_paths / launch_s / 1e12
             valu = {"bound": "valu", "achieved": tops, "peak": valu_peak, "unit": "Tlane-op/s", "frac": tops / valu_peak,
@@ -258,13 +296,13 @@ def main():
             hbm = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                    "basis": "FETCH_SIZE (doubled, as 16-byte-per-lane reads are tallied at half) + WRITE_SIZE of the kernel's launch, "
                             f"separate rocprofv3 --pmc passes ({traffic['source']}) / live kernel time"}
-        candidates = [r for r in (valu, hbm) if r is not None]
+        candidates = [r for r in (valu, l1, hbm) if r is not None]
         roofline = {"bound": "valu", "achieved": None, "peak": valu_peak, "unit": "Tlane-op/s", "frac": None}
         if candidates:
             roofline = dict(max(candidates, key=lambda r: r["frac"]))
         roofline.update({"traffic": hbm_bytes, "kernel": "trace_paths_kernel (+ sum_samples_kernel, 2% of the time)", "kernel_ms": launch_s * 1e3,
-                         "paths_per_launch": launch_paths, "valu": valu, "hbm": hbm,
-                         "counters_profiled_on": {"valu": work_from, "hbm": traffic_from}})
+                         "paths_per_launch": launch_paths, "valu": valu, "l1": l1, "hbm": hbm, "occupancy": occupancy,
+                         "counters_profiled_on": {"valu": work_from, "l1": work_from, "hbm": traffic_from}})
 
         work, work_key = algorithmic_work(scene_name, w, h, args.max_bounces)
         executed = executed_steps(scene, host, w, h, args.stats_spp, args.max_bounces, device) if (world == 1 and args.stats_spp > 0) else None
@@ -290,6 +328,10 @@ def main():
                        "parallelism": f"rows in blocks of 8 round-robin over {world} GPU(s), scene replicated, one gather to rank 0"
                                       + ("" if backend == "nccl" or world == 1 else f" (rehearsal: {backend}, ranks share GPUs)")},
             "roofline": roofline, "executed": executed, "algorithmic": algorithmic,
+            "per_rank": None if per_rank is None else dict(per_rank, kernel_ms_min=min(per_rank["kernel_ms"]), kernel_ms_max=max(per_rank["kernel_ms"]),
+                                                           gather_ms_max=max(per_rank["gather_ms"]),
+                                                           note="means over the timed steps; kernel = HIP events around each rank's launch, gather = events around "
+                                                                "its pack + gather + unpack on the rank's stream (rank 0 receives and unpacks)"),
             "setup_seconds": {"load_and_bvh_build": t1 - t0, "flatten_and_upload": t2 - t1},
         }
         # the timed region's own output against the CPU checker (rank 0 holds every rank's rows after the gather)

@@ -229,10 +229,19 @@ int pt_render(PtScene* scene, const PtFrame* frame, double* accum);
 /* Same, with `accum_device` in the HBM of the scene's device and the work
  * enqueued on `hip_stream` (a hipStream_t; null = the default stream).  Returns
  * after the launch; the caller synchronises the stream.  A scene handle owns one work counter and
- * one colour workspace: launches through one handle must be ordered (one stream, or waited for).
- * A launch on a different stream while the handle's previous launch is still running returns
- * PT_ERR_UNSUPPORTED and renders nothing; overlapping frames need one handle each. */
+ * one colour workspace, so its launches run one after another: those on one stream in stream order, and a
+ * launch on another stream (the null stream included: pt_render and pt_primary_hits use it) is put behind
+ * the end of the handle's previous launch (hipStreamWaitEvent).  Frames meant to overlap take one handle each.
+ * The workspace (per-path colour records: 32 bytes x pixels of the call's rows x samples, in batches when that
+ * is more than the limit) is allocated on demand and kept by the handle until pt_scene_destroy or a lower
+ * pt_scene_set_workspace_limit. */
 int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
+
+/* Cap, in bytes, of the device memory the handle keeps for its per-path colour records (default 24 GiB; the
+ * least a launch takes is one group of 16 samples of its rows, 0.5 KiB per pixel).  A smaller cap means more
+ * sample batches per launch, never other bytes.  What the handle holds beyond a lowered cap is freed at once
+ * (after its launches have finished).  Not in the reference (which keeps no per-sample state). */
+int pt_scene_set_workspace_limit(PtScene* scene, uint64_t bytes);
 
 /* One iteration of the reference's frame loop without the window (src/main.cpp:890-1036): the controls in
  * `input` (may be null: nothing pressed) are applied to *camera; if that changed it, `accum_device` (4*width*height
@@ -244,7 +253,7 @@ int pt_render_device(PtScene* scene, const PtFrame* frame, double* accum_device,
 int pt_viewer_frame(PtScene* scene, PtCamera* camera, const PtViewerInput* input, double aspect_ratio, int32_t width, int32_t height,
                     int32_t samples_per_frame, int32_t* sample, double* accum_device, void* hip_stream);
 
-/* pt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+/* pt_render_device for callers that cannot allocate device memory (a stream under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
  * bytes in `accum_device`; the per-path colour records and the work counter live in a workspace that is
  * part of the library's code object (PT_NOALLOC_MAX_TILES * 32 KiB + 1 KiB of HBM on every GPU the library
@@ -253,7 +262,11 @@ int pt_viewer_frame(PtScene* scene, PtCamera* camera, const PtViewerInput* input
  * (524,288 pixels, e.g. 1920 x 272 rows); beyond it PT_ERR_UNSUPPORTED is returned and nothing is rendered
  * - split the frame into row ranges.  Any sample count is taken (16 samples per pixel pass through the
  * workspace at a time).  All calls on one GPU share that GPU's workspace, whatever scene handle they go
- * through: calls that overlap in time on one GPU race; order them on one stream or with events. */
+ * through: each call is put behind the end of the one before it on that GPU (an event of the library's own),
+ * so calls from different handles or streams run one after another.  On a stream that is being captured the
+ * call enqueues its kernels and memsets only (no event is recorded, queried or waited for, and pt_last_render_ms
+ * has nothing to report): the graph orders what it holds, and replays of graphs that use the workspace must
+ * not overlap each other or other calls on that GPU. */
 enum { PT_NOALLOC_MAX_TILES = 8192 };
 int pt_render_device_noalloc(PtScene* scene, const PtFrame* frame, double* accum_device, void* hip_stream);
 
@@ -274,6 +287,11 @@ int pt_primary_hits(PtScene* scene, const PtFrame* frame, int32_t* triangle_inde
  * this scene (pt_viewer_frame and pt_primary_hits launch too and count), measured with HIP events
  * on the launch stream (blocks until the launch has finished).  Not in the reference: measurement only. */
 int pt_last_render_ms(PtScene* scene, float* ms);
+
+/* The shape of the handle's most recent wavefront launch (measurement only, not in the reference): persistent
+ * blocks of 256 threads per compute unit (= waves per SIMD, of the 8 the hardware holds), compute units of the
+ * device, and the bytes of colour workspace the handle holds.  Any pointer may be null. */
+int pt_last_launch_shape(PtScene* scene, int32_t* blocks_per_cu, int32_t* compute_units, uint64_t* workspace_bytes);
 
 /* Profiling aid, not in the reference: with PT_STATS=1 in the environment the wavefront kernel
  * counts its phases; `out` holds 16 values: node phases, lanes active in them, leaf phases,

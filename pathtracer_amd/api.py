@@ -21,6 +21,7 @@ EXPORTS = [
     "pt_host_scene_build", "pt_host_scene_desc", "pt_host_scene_camera", "pt_host_scene_destroy", "pt_tonemap_bgra8", "pt_tonemap_device",
     "pt_write_pixel_data_file", "pt_write_ppm_file", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_device_noalloc", "pt_primary_hits", "pt_last_render_ms", "pt_last_render_stats", "pt_device_eval",
+    "pt_scene_set_workspace_limit", "pt_last_launch_shape",
 ]
 
 
@@ -81,6 +82,8 @@ def lib():
         dll.pt_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         dll.pt_last_render_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         dll.pt_last_render_stats.argtypes = [C.c_void_p, C.c_void_p]
+        dll.pt_scene_set_workspace_limit.argtypes = [C.c_void_p, C.c_uint64]
+        dll.pt_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         dll.pt_device_eval.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = dll
     return _lib
@@ -281,6 +284,16 @@ class DeviceScene:
         ms = C.c_float()
         check(lib().pt_last_render_ms(self.handle, C.byref(ms)))
         return ms.value
+
+    def set_workspace_limit(self, nbytes):
+        """Cap of the device memory the handle keeps for its per-path colour records."""
+        check(lib().pt_scene_set_workspace_limit(self.handle, int(nbytes)))
+
+    def last_launch_shape(self):
+        """(persistent blocks per compute unit = waves per SIMD, compute units, bytes of colour workspace held)."""
+        blocks, units, held = C.c_int32(), C.c_int32(), C.c_uint64()
+        check(lib().pt_last_launch_shape(self.handle, C.byref(blocks), C.byref(units), C.byref(held)))
+        return blocks.value, units.value, held.value
 
     def last_render_stats(self):
         out = np.zeros(16, np.uint64)

@@ -56,7 +56,7 @@ class SortTeam {
 public:
     static void sort(KeyedIndex* first, KeyedIndex* last, int threads) {
 #if defined(__GLIBCXX__)
-        if (threads > 1 && last - first > 2 * GRAIN) {
+        if (threads > 1 && last - first > 2 * GRAIN && same_as_the_library()) {
             SortTeam team;
             team.tasks.push_back(Task{first, last, static_cast<long>(std::__lg(last - first)) * 2});
             std::vector<std::thread> others;
@@ -72,6 +72,33 @@ public:
 
 private:
     static constexpr long GRAIN = 1 << 14;       // ranges up to this long are finished by the thread that has them
+#if defined(__GLIBCXX__)
+    // The team's steps are the internals of this libstdc++'s std::sort.  Should another release change them (the
+    // threshold, the pivot rule, the final pass), the team's permutation of equal keys could differ from std::sort's
+    // without any error: so, once per process, both sort one array of 100,000 keys of which almost all tie, and the
+    // team is used only if the two orders are the same.
+    static bool same_as_the_library() {
+        static const bool same = []() {
+            const int n = 100000;
+            std::vector<KeyedIndex> plain(n), shared(n);
+            unsigned state = 12345u;
+            for (int i = 0; i < n; ++i) {
+                state = state * 1664525u + 1013904223u;
+                plain[i] = shared[i] = KeyedIndex{static_cast<double>((state >> 16) % 37u), i};
+            }
+            std::sort(plain.begin(), plain.end(), key_less);
+            SortTeam team;
+            team.tasks.push_back(Task{shared.data(), shared.data() + n, static_cast<long>(std::__lg(n)) * 2});
+            std::vector<std::thread> others;
+            for (int t = 1; t < 3; ++t) others.emplace_back([&team]() { team.work(); });
+            team.work();
+            for (std::thread& t : others) t.join();
+            for (int i = 0; i < n; ++i) if (plain[i].index != shared[i].index) return false;
+            return true;
+        }();
+        return same;
+    }
+#endif
     struct Task { KeyedIndex* first; KeyedIndex* last; long depth; };
     std::mutex lock;
     std::condition_variable changed;

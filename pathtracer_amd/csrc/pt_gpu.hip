@@ -236,8 +236,16 @@ struct DeviceBuffer {
 };
 
 constexpr int MAX_DEVICES = 64;
+// What a scene handle may keep of device memory for its per-path colour records unless its owner says otherwise: the
+// benchmark frame (1920 x 1080 x 256 samples, 17 GB) fits; longer sample ranges run in batches (3840 x 2160 x 1024: 11 of them,
+// 4 % slower than through 96 GB).
+constexpr size_t DEFAULT_WORKSPACE_BYTES = size_t(24) << 30;
 std::mutex static_scratch_lock;
 void* static_scratch_address[MAX_DEVICES] = {};     // per device, resolved once with that device current
+// Every scene handle of a device shares that device's static workspace: each launch that uses it waits for the end of the
+// one before (this event, recorded behind every such launch), whatever handles and streams the two came from.
+hipEvent_t static_scratch_free[MAX_DEVICES] = {};
+bool static_scratch_used[MAX_DEVICES] = {};
 
 // Address of `device`'s copy of the static workspace (the device must be current).
 int static_scratch_of(int device, void** out) {
@@ -247,6 +255,7 @@ int static_scratch_of(int device, void** out) {
         void* address = nullptr;
         HIP_TRY(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
         if (address == nullptr) return pt::fail(PT_ERR_DEVICE, "hipGetSymbolAddress gave no address for the static workspace on device %d", device);
+        HIP_TRY(hipEventCreateWithFlags(&static_scratch_free[device], hipEventDisableTiming));
         static_scratch_address[device] = address;
     }
     *out = static_scratch_address[device];
@@ -412,6 +421,7 @@ struct PtScene {
     // wavefront kernel: per-path colours, the chunk counter and the profiling counters
     DeviceBuffer rgb, counters;
     size_t rgb_bytes = 0;
+    size_t workspace_limit = DEFAULT_WORKSPACE_BYTES;   // cap of `rgb` (pt_scene_set_workspace_limit)
     void* last_counters = nullptr;      // counters of the most recent wavefront launch (the scene's own or the static workspace's)
     void* static_workspace = nullptr;   // this device's copy of the static workspace (pt_render_device_noalloc)
     bool albedo_bounded = false;        // every albedo finite with |albedo| <= 1
@@ -642,7 +652,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void tonemap_kernel(const double* __
 struct Tunables {
     bool force_pixels_kernel = false;   // PT_KERNEL=pixels: always the one-lane-per-pixel kernel
     int stats = 0;                      // PT_STATS=1: phase/lane counters + box-test cross-check; 2: counters + per-section clocks
-    double workspace_gb = 96.0;         // PT_WORKSPACE_GB: cap of the per-path colour buffer (a third of the 288 GB; also bounded by what is free)
+    double workspace_gb = -1.0;         // PT_WORKSPACE_GB: overrides the scene's cap of the per-path colour buffer (pt_scene_set_workspace_limit)
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
@@ -726,7 +736,7 @@ struct Workspace {
 // has (down to `least`): a smaller workspace only means more sample batches, never other bytes.
 int grow_workspace(PtScene* scene, size_t want, size_t least) {
     if (scene->counters.p == nullptr) HIP_TRY(hipMalloc(&scene->counters.p, 1024));
-    if (scene->rgb_bytes >= want) return PT_OK;
+    if (scene->rgb_bytes >= want) return PT_OK;      // (a buffer larger than a lowered limit was released by pt_scene_set_workspace_limit)
     if (scene->rgb.p != nullptr) { HIP_TRY(hipFree(scene->rgb.p)); scene->rgb.p = nullptr; scene->rgb_bytes = 0; }
     size_t free_bytes = 0, total_bytes = 0;
     HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
@@ -757,7 +767,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
                             "(render the frame in several row ranges)", real_tiles, static_cast<long long>(ws.rgb_bytes / (4 * CHUNK_PATHS * sizeof(double))));
         }
     } else {
-        const size_t cap = static_cast<size_t>(t.workspace_gb * 1024.0 * 1024.0 * 1024.0);
+        const size_t cap = t.workspace_gb >= 0.0 ? static_cast<size_t>(t.workspace_gb * 1024.0 * 1024.0 * 1024.0) : scene->workspace_limit;
         const size_t wanted_groups = std::min<size_t>(std::max<size_t>(1, cap / bytes_per_group), total_groups);
         const int rc = grow_workspace(scene, bytes_per_group * wanted_groups, bytes_per_group);
         if (rc != PT_OK) return rc;
@@ -837,26 +847,34 @@ bool wavefront_serves(const PtScene* scene) {
 int launch_render(PtScene* scene, const PtFrame* frame, double* accum_device, hipStream_t stream, Workspace ws) {
     if (frame->row_begin == frame->row_end || frame->sample_count == 0 || grid_blocks(*frame) == 0) return PT_OK;
     HIP_TRY(hipSetDevice(scene->device));
-    // A handle owns one work counter, one colour workspace and one pair of timing events: a launch on
-    // another stream while the previous one is still running would share them.  Launches on one stream
-    // are ordered by the stream and need no check.
-    if (scene->timed && stream != scene->last_stream) {
-        const hipError_t previous = hipEventQuery(scene->stop);
-        if (previous == hipErrorNotReady) {
-            (void)hipGetLastError();
-            return pt::fail(PT_ERR_UNSUPPORTED, "the previous launch on this scene handle is still running on another stream: "
-                            "wait for it, use one stream per handle, or create a second handle for overlapping launches");
-        }
-        if (previous != hipSuccess) return pt::fail(PT_ERR_DEVICE, "hipEventQuery: %s", hipGetErrorString(previous));
+    // A stream that is being captured into a graph takes the kernels and the memsets only: events recorded outside the
+    // capture may not be queried or waited for there, and the graph itself orders what it holds.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (stream != nullptr) HIP_TRY(hipStreamIsCapturing(stream, &capture));
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    // A handle owns one work counter, one colour workspace and one pair of timing events.  Launches on one stream are
+    // ordered by the stream; a launch on another stream is put behind the end of the handle's previous launch.  (Frames
+    // that are meant to overlap take one handle each.)
+    if (!capturing && scene->timed && stream != scene->last_stream) HIP_TRY(hipStreamWaitEvent(stream, scene->stop, 0));
+    if (!capturing && ws.fixed) {
+        std::lock_guard<std::mutex> guard(static_scratch_lock);
+        if (static_scratch_used[scene->device]) HIP_TRY(hipStreamWaitEvent(stream, static_scratch_free[scene->device], 0));
     }
     scene->has_stats = false;
-    HIP_TRY(hipEventRecord(scene->start, stream));
+    scene->timed = false;        // until this launch is enqueued in full there is no pair of events to read a time from
+    if (!capturing) HIP_TRY(hipEventRecord(scene->start, stream));
     // The wavefront kernel needs bounded albedos and at least one bounce (see pt_wavefront.hpp);
     // anything else goes through the one-lane-per-pixel kernel, which carries the colour explicitly.
     const bool wavefront = frame->max_bounces >= 1 && wavefront_serves(scene);
     const int rc = wavefront ? launch_wavefront(scene, frame, accum_device, stream, ws) : launch_pixels_kernel(scene, frame, accum_device, stream);
     if (rc != PT_OK) return rc;
+    if (capturing) return PT_OK;
     HIP_TRY(hipEventRecord(scene->stop, stream));
+    if (ws.fixed) {
+        std::lock_guard<std::mutex> guard(static_scratch_lock);
+        HIP_TRY(hipEventRecord(static_scratch_free[scene->device], stream));
+        static_scratch_used[scene->device] = true;
+    }
     scene->last_stream = stream;
     scene->timed = true;
     return PT_OK;
@@ -984,27 +1002,60 @@ int pt_viewer_frame(PtScene* scene, PtCamera* camera, const PtViewerInput* input
                     int32_t samples_per_frame, int32_t* sample, double* accum_device, void* hip_stream) {
     if (scene == nullptr || camera == nullptr || sample == nullptr || accum_device == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_viewer_frame: null argument");
     if (samples_per_frame < 1 || *sample < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_viewer_frame: samples_per_frame must be positive and *sample non-negative");
+    // Nothing of the caller's changes unless the frame is enqueued: the controls move a copy of the camera, and the copy,
+    // the sample counter and (where the camera moved) the cleared buffer are handed back together at the end.
+    PtCamera moved = *camera;
     int32_t modified = 0;
     if (input != nullptr) {
-        const int rc = pt_camera_apply_input(camera, input, &modified);
+        const int rc = pt_camera_apply_input(&moved, input, &modified);
         if (rc != PT_OK) return rc;
     }
     PtFrame frame;
-    int rc = pt_camera_frame(camera, aspect_ratio, width, height, &frame);                     // src/main.cpp:987-994
+    int rc = pt_camera_frame(&moved, aspect_ratio, width, height, &frame);                     // src/main.cpp:987-994
     if (rc != PT_OK) return rc;
     rc = check_frame(&frame);
     if (rc != PT_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     HIP_TRY(hipSetDevice(scene->device));
-    if (modified != 0) {                                                                       // :996-999
-        HIP_TRY(hipMemsetAsync(accum_device, 0, 4ull * width * height * sizeof(double), stream));
-        *sample = 0;
-    }
-    frame.sample_begin = *sample;
+    const int32_t first_sample = modified != 0 ? 0 : *sample;                                  // :996-999
+    frame.sample_begin = first_sample;
     frame.sample_count = samples_per_frame;
+    if (modified != 0) {
+        // the buffer is cleared on the frame's own stream, ahead of its kernels; should the launch then be refused, the
+        // buffer is cleared and the camera and the counter are not moved: the caller's next frame starts the picture anew
+        // from the camera he still holds, which is what a cleared buffer asks for
+        HIP_TRY(hipMemsetAsync(accum_device, 0, 4ull * width * height * sizeof(double), stream));
+    }
     rc = launch_render(scene, &frame, accum_device, stream, Workspace{});                      // :1001-1022
-    if (rc != PT_OK) return rc;
-    *sample += samples_per_frame;                                                              // :1036
+    if (rc != PT_OK) {
+        if (modified != 0) *sample = 0;       // the buffer holds no sample any more
+        return rc;
+    }
+    *camera = moved;
+    *sample = first_sample + samples_per_frame;                                                // :1036
+    return PT_OK;
+}
+
+int pt_scene_set_workspace_limit(PtScene* scene, uint64_t bytes) {
+    if (scene == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_scene_set_workspace_limit: null scene");
+    HIP_TRY(hipSetDevice(scene->device));
+    scene->workspace_limit = static_cast<size_t>(bytes);
+    if (scene->rgb.p != nullptr && scene->rgb_bytes > scene->workspace_limit) {
+        // what the handle holds beyond the new limit goes back to the device now (after the launches that use it)
+        if (scene->timed) HIP_TRY(hipEventSynchronize(scene->stop));
+        HIP_TRY(hipFree(scene->rgb.p));
+        scene->rgb.p = nullptr;
+        scene->rgb_bytes = 0;
+    }
+    return PT_OK;
+}
+
+int pt_last_launch_shape(PtScene* scene, int32_t* blocks_per_cu, int32_t* compute_units, uint64_t* workspace_bytes) {
+    if (scene == nullptr) return pt::fail(PT_ERR_INVALID_ARGUMENT, "pt_last_launch_shape: null scene");
+    if (scene->compute_units == 0) return pt::fail(PT_ERR_UNSUPPORTED, "pt_last_launch_shape: this handle has not run the wavefront kernel yet");
+    if (blocks_per_cu != nullptr) *blocks_per_cu = scene->blocks_per_cu;
+    if (compute_units != nullptr) *compute_units = scene->compute_units;
+    if (workspace_bytes != nullptr) *workspace_bytes = scene->rgb_bytes;
     return PT_OK;
 }
 

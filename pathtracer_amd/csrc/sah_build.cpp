@@ -26,9 +26,12 @@ namespace pt {
 namespace {
 
 constexpr int MAX_BINS = 64;
-int BINS = 32;                        // bins per axis of a split (PT_SAH_BINS overrides, at most MAX_BINS; 16 -> 32: 0.6 % fewer node steps and triangle tests)
-
-double COUNT_POWER = 1.0;             // a side of n leaves weighs n^COUNT_POWER in a split's cost (PT_SAH_POWER; 1 = the usual surface-area heuristic)
+// Both are read from the environment once, when the library is loaded: threads that create scenes at the same time all
+// see the same values.
+// bins per axis of a split (PT_SAH_BINS overrides, at most MAX_BINS; 16 -> 32: 0.6 % fewer node steps and triangle tests)
+const int BINS = []() { const char* v = std::getenv("PT_SAH_BINS"); return v != nullptr ? std::min(MAX_BINS, std::max(2, std::atoi(v))) : 32; }();
+// a side of n leaves weighs n^COUNT_POWER in a split's cost (PT_SAH_POWER; 1 = the usual surface-area heuristic)
+const double COUNT_POWER = []() { const char* v = std::getenv("PT_SAH_POWER"); return v != nullptr ? std::atof(v) : 1.0; }();
 inline double weight(int n) { return COUNT_POWER == 1.0 ? static_cast<double>(n) : std::pow(static_cast<double>(n), COUNT_POWER); }
 
 inline PtAabb empty_box() {
@@ -281,8 +284,6 @@ int host_threads() {
 
 int build_sah_pairs(const PtAabb* boxes, int count, int max_height, UnfilledVector<ptd::PairNodeHost>* pairs, int* root_ref,
                     int* height_out) {
-    if (const char* v = std::getenv("PT_SAH_BINS")) BINS = std::min(MAX_BINS, std::max(2, std::atoi(v)));
-    if (const char* v = std::getenv("PT_SAH_POWER")) COUNT_POWER = std::atof(v);
     if (count <= 0) return fail(PT_ERR_INVALID_ARGUMENT, "build_sah_pairs: no boxes");
     if (levels_for(count) > max_height) return fail(PT_ERR_UNSUPPORTED, "%d leaves cannot fit a tree of height %d", count, max_height);
     pairs->resize(count > 1 ? count - 1 : 0);      // every pair is written in full by build()

@@ -8,8 +8,6 @@ byte-identical to a single-GPU render.  The only exchange is the final gather of
 rows to rank 0 (RCCL over xGMI on GPUs, gloo on CPU): 32 B per pixel, once per frame, or 4 B per
 pixel when only the tone-mapped image is wanted (`gather_image8`).
 """
-import functools
-
 import torch
 import torch.distributed as dist
 
@@ -23,18 +21,14 @@ def shard_rows(height, rank, world, row_begin=0):
     return rows[block % world == rank]
 
 
-@functools.lru_cache(maxsize=64)
-def _rows_on_device(height, rank, world, device):
-    """shard_rows(...) as an index tensor on `device`, made once: a frame loop calls the gather every frame."""
-    return shard_rows(height, rank, world).to(device)
-
-
-def pack_rows(accum, rows, length):
+def pack_rows(accum, rows, length, out=None):
     """The send buffer of one rank: its rows of `accum` (row indices `rows`, a tensor on accum's device),
-    packed in ascending order into `length` rows (every rank sends the same size; the tail is zero)."""
-    send = torch.zeros((length,) + tuple(accum.shape[1:]), dtype=accum.dtype, device=accum.device)
-    send[: len(rows)] = accum.index_select(0, rows)
-    return send
+    packed in ascending order into `length` rows (every rank sends the same size; the tail is zero).
+    `out`, if given, is a buffer from an earlier call for the same arguments: nothing is allocated then."""
+    if out is None:
+        out = torch.zeros((length,) + tuple(accum.shape[1:]), dtype=accum.dtype, device=accum.device)
+    torch.index_select(accum, 0, rows, out=out[: len(rows)])
+    return out
 
 
 def unpack_rows(accum, rows, received):
@@ -43,25 +37,44 @@ def unpack_rows(accum, rows, received):
     return accum
 
 
+class RowGather:
+    """The gather of one frame size, with its index tensors and its send and receive buffers made once: a frame loop
+    calls it every frame, and nothing is allocated inside the loop."""
+
+    def __init__(self, height, width, dtype, device, rank, world, dst=0, group=None):
+        self.shape, self.rank, self.world, self.dst, self.group = (height, width, 4), rank, world, dst, group
+        self.rows_of = [shard_rows(height, r, world).to(device) for r in range(world)]
+        longest = max(len(rows) for rows in self.rows_of)
+        self.send = torch.zeros((longest, width, 4), dtype=dtype, device=device)
+        self.received = [torch.empty_like(self.send) for _ in range(world)] if rank == dst else None
+
+    def __call__(self, accum):
+        assert tuple(accum.shape) == self.shape and accum.dtype == self.send.dtype and accum.device == self.send.device
+        pack_rows(accum, self.rows_of[self.rank], len(self.send), out=self.send)
+        dist.gather(self.send, self.received, dst=self.dst, group=self.group)
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.dst:
+                    unpack_rows(accum, self.rows_of[r], self.received[r])
+        return accum
+
+
+_gathers = {}
+
+
 def gather_rows(accum, height, width, rank, world, dst=0, group=None):
     """accum: (height, width, 4) tensor (float64 sums, or uint8 image) holding this rank's rows
     (others are ignored).  After the call rank `dst` holds every rank's rows in place; other ranks
-    are unchanged."""
+    are unchanged.  The buffers of a (size, type, device, rank, world) are made at the first call and kept."""
     if world == 1:
         return accum
     assert accum.shape == (height, width, 4)
-    rows_of = [_rows_on_device(height, r, world, accum.device) for r in range(world)]
-    longest = max(len(rows) for rows in rows_of)
-    send = pack_rows(accum, rows_of[rank], longest)
-    if rank == dst:
-        received = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, received, dst=dst, group=group)
-        for r in range(world):
-            if r != dst:
-                unpack_rows(accum, rows_of[r], received[r])
-    else:
-        dist.gather(send, None, dst=dst, group=group)
-    return accum
+    key = (height, width, accum.dtype, accum.device, rank, world, dst, id(group))
+    if key not in _gathers:
+        if len(_gathers) >= 16:
+            _gathers.clear()
+        _gathers[key] = RowGather(height, width, accum.dtype, accum.device, rank, world, dst, group)
+    return _gathers[key](accum)
 
 
 def gather_image8(accum, sample_count, height, width, rank, world, dst=0, group=None):

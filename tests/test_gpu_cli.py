@@ -58,29 +58,55 @@ def test_a_c_program_built_against_the_header_renders_the_reference_frame(golden
     assert same_bits(accum, golden["rook_accum4"].ravel())
 
 
-def test_a_second_launch_on_a_busy_handle_from_another_stream_is_refused(api):
-    """A scene handle owns one work counter and one colour workspace: a launch on another stream while the
-    previous one still runs returns PT_ERR_UNSUPPORTED and renders nothing; after the first has finished
-    the same call goes through, and launches on one stream simply queue."""
+def test_launches_through_one_handle_from_several_streams_run_one_after_another(api):
+    """A scene handle owns one work counter and one colour workspace: a launch on another stream is put behind the
+    end of the handle's previous launch instead of running beside it (it would share the counter), and the null
+    stream's entry points (pt_primary_hits, pt_render) may follow an asynchronous launch at once."""
     import torch
     host = api.HostScene(abi.PT_SCENE_CHESS32, MODELS)
     device = api.DeviceScene.from_host(host)
     frame = host.frame(1920, 1080, sample_count=64)        # some tens of milliseconds of work
     a = torch.zeros((1080, 1920, 4), dtype=torch.float64, device="cuda:0")
     b = torch.zeros_like(a)
+    c = torch.zeros_like(a)
     torch.cuda.synchronize()
     first, second = torch.cuda.Stream(), torch.cuda.Stream()
     device.render_device(frame, a.data_ptr(), first.cuda_stream)
-    with pytest.raises(api.PathTracerError) as refused:
-        device.render_device(frame, b.data_ptr(), second.cuda_stream)
-    assert refused.value.code == abi.PT_ERR_UNSUPPORTED
-    device.render_device(frame, b.data_ptr(), first.cuda_stream)      # same stream: ordered behind the first
+    device.render_device(frame, b.data_ptr(), second.cuda_stream)     # while the first still runs: ordered behind it
+    device.render_device(frame, c.data_ptr(), first.cuda_stream)
+    small = host.frame(96, 54, sample_count=1)
+    tri, _ = device.primary_hits(small)                               # null stream, right behind three asynchronous launches
     torch.cuda.synchronize()
-    assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and bool((a[..., 3] == 64.0).all())
-    b.zero_()
-    device.render_device(frame, b.data_ptr(), second.cuda_stream)     # the handle is idle now
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and torch.equal(a.view(torch.int64), c.view(torch.int64))
+    assert bool((a[..., 3] == 64.0).all()) and (tri >= 0).any()
+    blocks, units, held = device.last_launch_shape()
+    assert 1 <= blocks <= 8 and units > 0 and held >= 1920 * 1080 * 16 * 32
+
+
+def test_workspace_limit_changes_batches_not_bytes(api):
+    """pt_scene_set_workspace_limit: the cap of what a handle keeps for its per-path colour records.  A cap below one
+    launch's need only means more sample batches; a lowered cap gives the memory back."""
+    import torch
+    host = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
+    device = api.DeviceScene.from_host(host)
+    frame = host.frame(640, 360, sample_count=80)
+    group_bytes = 80 * 45 * 1024 * 32                      # 16 samples of the 80 x 45 tiles
+    whole = torch.zeros((360, 640, 4), dtype=torch.float64, device="cuda:0")
+    device.render_device(frame, whole.data_ptr())
     torch.cuda.synchronize()
-    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert device.last_launch_shape()[2] == 5 * group_bytes
+    device.set_workspace_limit(2 * group_bytes + 5)
+    assert device.last_launch_shape()[2] == 0              # what it held beyond the new cap is released
+    batched = torch.zeros_like(whole)
+    device.render_device(frame, batched.data_ptr())
+    torch.cuda.synchronize()
+    assert device.last_launch_shape()[2] == 2 * group_bytes
+    assert torch.equal(whole.view(torch.int64), batched.view(torch.int64))
+    device.set_workspace_limit(0)                          # one group is the least a launch takes
+    batched.zero_()
+    device.render_device(frame, batched.data_ptr())
+    torch.cuda.synchronize()
+    assert device.last_launch_shape()[2] == group_bytes and torch.equal(whole.view(torch.int64), batched.view(torch.int64))
 
 
 def test_bench_script_with_two_ranks_on_one_gpu(tmp_path):
@@ -108,6 +134,11 @@ def test_bench_script_with_two_ranks_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["verified"] is True
     assert line["value"] > 0 and line["unit"] == "Msamples/s" and line["scaling"] == "strong"
     assert line["roofline"]["paths_per_launch"] == 640 * 360 * 16 / 2
+    # every rank's own kernel and gather times are in the line (what shows imbalance once the ranks have a GPU each)
+    ranks = line["per_rank"]
+    assert len(ranks["kernel_ms"]) == 2 and len(ranks["gather_ms"]) == 2 and min(ranks["kernel_ms"]) > 0
+    assert ranks["kernel_ms_min"] == min(ranks["kernel_ms"]) and ranks["kernel_ms_max"] == max(ranks["kernel_ms"]) and ranks["gather_ms_max"] > 0
+    assert line["roofline"]["occupancy"]["waves_per_simd"] >= 1
 
 
 def test_viewer_frames_accumulate_and_restart_like_the_reference_loop(api, orc):

@@ -12,29 +12,9 @@ from pathtracer_amd import ctypes_abi as abi
 
 pytestmark = pytest.mark.gpu
 
-SKY = np.array([[1.0, 1.0, 1.0], [0.5, 0.7, 1.0]])
-
-
-def _materials():
-    m = np.zeros(4, abi.MATERIAL_DTYPE)
-    m[0]["v"] = [0.8, 0.6, 0.4, 0.0]                                   # lambertian
-    m[1]["v"] = [0.9, 0.9, 0.8, 0.2]; m[1]["type"] = abi.PT_METAL
-    m[2]["v"] = [1.5, 0.0, 0.0, 0.0]; m[2]["type"] = abi.PT_DIELECTRIC
-    m[3]["v"] = [1.0, 0.9, 0.8, 5.0]; m[3]["type"] = abi.PT_DIFFUSE_LIGHT
-    return m
-
-
-def _scene(api, triangles=None, spheres=None, tri_materials=None, sph_materials=None):
-    triangles = np.zeros((0, 9)) if triangles is None else np.asarray(triangles, float).reshape(-1, 9)
-    spheres = np.zeros((0, 4)) if spheres is None else np.asarray(spheres, float).reshape(-1, 4)
-    arrays = {"materials": _materials(), "triangles": triangles, "spheres": spheres, "background": SKY,
-              "triangle_material_indices": np.asarray(tri_materials if tri_materials is not None else np.arange(len(triangles)) % 4, np.int32),
-              "sphere_material_indices": np.asarray(sph_materials if sph_materials is not None else np.arange(len(spheres)) % 3, np.int32)}
-    if len(triangles):
-        arrays["triangle_bvh"] = api.construct_triangle_bvh(triangles)
-    if len(spheres):
-        arrays["sphere_bvh"] = api.construct_sphere_bvh(spheres)
-    return arrays
+from campaign import SKY, random_frame, random_scene  # noqa: F401
+from campaign import materials as _materials  # noqa: F401
+from campaign import scene_arrays as _scene
 
 
 def _compare(api, orc, arrays, eye, target, size=(40, 30), spp=3, bounces=12, aperture=0.05, own_trees=True):
@@ -180,44 +160,8 @@ def test_random_scenes_against_the_checker(api, orc, seed):
     """Seeded random scenes of every shape the library takes: triangle soups of 1..400 triangles (some on an integer
     lattice, so that coplanar and duplicated triangles tie), 0..40 spheres (hollow ones in every fourth scene), all
     four materials, cameras inside and outside the geometry, odd image sizes.  Primary hit indices and buffers, bit for bit."""
-    rng = np.random.default_rng(1000 + seed)
-    count = int(rng.choice([1, 2, 7, 33, 150, 400] if seed < 16 else [1, 2, 7, 33, 150, 400, 3000, 30000]))
-    if seed % 3 == 0:
-        base = rng.integers(-6, 7, (count, 1, 3)).astype(float)
-        triangles = (base + rng.integers(0, 3, (count, 3, 3))).reshape(-1, 9)          # lattice: exact ties and degenerate triangles
-        triangles = np.concatenate([triangles, triangles[: max(1, count // 5)]])            # and exact duplicates
-    else:
-        centre = rng.uniform(-8, 8, (count, 1, 3))
-        triangles = (centre + rng.normal(0, rng.uniform(0.2, 3.0), (count, 3, 3))).reshape(-1, 9)
-    spheres = None
-    if seed % 2 == 1:
-        n = int(rng.choice([1, 2, 5, 40]))
-        spheres = np.concatenate([rng.uniform(-8, 8, (n, 3)), rng.uniform(0.3, 2.5, (n, 1))], 1)
-        if seed % 4 == 3:
-            spheres[::2, 3] *= -1.0                                                    # hollow: inverted boxes
-        if seed % 6 == 3 and seed >= 16:
-            spheres = np.concatenate([rng.integers(-6, 7, (n, 3)), rng.integers(1, 3, (n, 1))], 1).astype(float)   # on the triangles' lattice
-            spheres = np.concatenate([spheres, spheres[: max(1, n // 3)]])                                         # and duplicated: tied spheres
-    if seed % 11 == 5:                                                                 # unbounded and huge coordinates
-        odd = np.array([np.inf, -np.inf, 1e300, -1e300, 1e160, 3e6])
-        hit = rng.random(triangles.shape) < 0.01
-        triangles[hit] = rng.choice(odd, hit.sum())
-        if spheres is not None:
-            spheres[rng.integers(0, len(spheres)), rng.integers(0, 4)] = rng.choice(odd)
-    arrays = _scene(api, triangles, spheres, tri_materials=rng.integers(0, 4, len(triangles)),
-                    sph_materials=None if spheres is None else rng.integers(0, 4, len(spheres)))
-    if seed % 7 == 6:                                                                  # any numbers as material parameters
-        values = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1.5, 2.0, 1e-300, 1e300, np.inf, -np.inf, np.nan, 0.999, 1.0000001, 7.0])
-        materials = arrays["materials"].copy()
-        for m in materials:
-            m["v"] = np.where(rng.random(4) < 0.5, rng.choice(values, 4), rng.uniform(-0.2, 1.6, 4))
-        arrays["materials"] = materials
-    eye = tuple(rng.uniform(-4, 4, 3)) if seed % 5 == 0 else tuple(rng.uniform(12, 25, 3) * rng.choice([-1, 1], 3))
-    if seed % 12 == 9:
-        eye = tuple(float(v) for v in rng.integers(8, 20, 3) * rng.choice([-1, 1], 3))   # a lattice point: with aperture 0 every ray starts there
-    size = (int(rng.integers(9, 70)), int(rng.integers(9, 50)))
-    _compare(api, orc, arrays, eye, (0.0, 0.0, 0.0), size=size, spp=int(rng.integers(1, 4)), bounces=int(rng.choice([1, 4, 12, 50])),
-             aperture=float(rng.choice([0.0, 0.05, 0.6])))
+    arrays, how, _ = random_scene(api, seed)
+    _compare(api, orc, arrays, how["eye"], how["target"], size=how["size"], spp=how["spp"], bounces=how["bounces"], aperture=how["aperture"])
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PT_RANDOM_FRAMES", "12"))))
@@ -227,34 +171,11 @@ def test_random_frames_against_the_checker(api, orc, seed):
     at once, both kernels, into a buffer that already holds numbers.  Every double against the CPU checker.
     PT_RANDOM_FRAMES=<n> widens the campaign."""
     from oracle.bindings import make_desc
-    rng = np.random.default_rng(5000 + seed)
-    count = int(rng.choice([3, 40, 300]))
-    triangles = (rng.uniform(-7, 7, (count, 1, 3)) + rng.normal(0, rng.uniform(0.3, 2.5), (count, 3, 3))).reshape(-1, 9)
-    n = int(rng.choice([0, 1, 6]))
-    spheres = np.concatenate([rng.uniform(-7, 7, (n, 3)), rng.uniform(0.3, 2.0, (n, 1))], 1) if n else None
-    arrays = _scene(api, triangles, spheres, tri_materials=rng.integers(0, 4, count), sph_materials=None if spheres is None else rng.integers(0, 4, n))
+    arrays, frame, held, rng, _ = random_frame(api, seed)
+    width, height = frame.width, frame.height
     desc, keep = make_desc(arrays)
     device = api.DeviceScene(desc, keepalive=keep)
     checker = orc.scene_create(arrays)
-    width, height = int(rng.integers(2, 150)), int(rng.integers(2, 90))
-    cam = api.camera_look_at(tuple(rng.uniform(10, 24, 3) * rng.choice([-1, 1], 3)), (0.0, 0.0, 0.0), 0.7, float(rng.choice([0.0, 0.1])))
-    rows = sorted(int(v) for v in rng.integers(0, height + 1, 2))
-    if rows[0] == rows[1]:
-        rows = [0, height]
-    shards = int(rng.choice([1, 1, 2, 3, 5]))
-    frame = api.camera_frame(cam, width / height, width, height, row_begin=rows[0], row_end=rows[1],
-                             sample_begin=int(rng.integers(0, 40)), sample_count=int(rng.choice([1, 5, 16, 17, 33, 50])),
-                             max_bounces=int(rng.choice([0, 1, 3, 12, 50])), shard_count=shards, shard_index=int(rng.integers(0, shards)))
-    if seed % 13 == 4:                                   # any numbers in the camera: the rays may be NaN, infinite, parallel to an axis
-        values = np.array([0.0, -0.0, 1.0, -1.0, 1e-300, 1e160, 1e300, -1e300, np.inf, -np.inf, np.nan])
-        for name in ("camera_position", "camera_x", "camera_y", "bottom_left", "step_x", "step_y"):
-            vector = getattr(frame, name)
-            for axis in "xyz":
-                if rng.random() < 0.25:
-                    setattr(vector, axis, float(rng.choice(values)))
-        if rng.random() < 0.5:
-            frame.aperture = float(rng.choice([-1.0, 0.0, 1e300, np.inf, np.nan, 3.0]))
-    held = rng.uniform(0, 3, 4 * width * height)
     saved = {k: os.environ.pop(k, None) for k in ("PT_WORKSPACE_GB", "PT_KERNEL")}
     try:
         if seed % 2 == 1:

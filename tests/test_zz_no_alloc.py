@@ -68,3 +68,29 @@ def test_noalloc_rejects_frames_beyond_its_workspace(api):
         device.render_device_noalloc(host.frame(1920, 1080, sample_count=1, row_begin=begin, row_end=min(begin + 272, 1080)), buf.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(buf.view(torch.int64), expect.view(torch.int64))
+
+
+def test_noalloc_under_graph_capture(api):
+    """The entry point on a stream that is being captured into a HIP graph: nothing is allocated, no event is recorded or
+    queried, so the capture stays valid; two replays into a cleared buffer give the bytes of a plain launch each."""
+    import torch
+    host = api.HostScene(abi.PT_SCENE_CHESS6_ROW, MODELS)
+    device = api.DeviceScene.from_host(host)
+    frame = host.frame(320, 180, sample_count=20, max_bounces=50)
+    expect = torch.zeros((180, 320, 4), dtype=torch.float64, device="cuda:0")
+    device.render_device(frame, expect.data_ptr())
+    got = torch.zeros_like(expect)
+    device.render_device_noalloc(frame, got.data_ptr())     # what a handle sets up once (the occupancy query) happens here, outside the capture
+    torch.cuda.synchronize()
+    got.zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        device.render_device_noalloc(frame, got.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool((got == 0).all())                          # capturing runs nothing
+    for _ in range(2):
+        got.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int64), expect.view(torch.int64))
