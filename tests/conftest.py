@@ -23,6 +23,20 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def benchmark_golden():
+    """The benchmark's own scenes rendered by the reference's code (oracle/gen_benchmark_golden.py)."""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "benchmark_scenes.npz")))
+
+
+BENCHMARK_ROWS_1080P = (137, 540, 803)
+
+
+def sha256_of(array):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(array).tobytes()).digest(), np.uint8)
+
+
+@pytest.fixture(scope="session")
 def orc():
     """The CPU restatement (oracle/libpt_oracle.so): the checker, never the product."""
     from oracle.bindings import OracleLib, have_oracle

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MODELS, id_hash, same_bits
+from conftest import BENCHMARK_ROWS_1080P, MODELS, id_hash, same_bits, sha256_of
 from pathtracer_amd import ctypes_abi as abi
 from pathtracer_amd.ctypes_abi import PtFrame
 
@@ -257,10 +257,34 @@ def test_full_size_properties(scenes, api):
 
 def test_full_frame_matches_checker(scenes):
     """The whole 1920x1080 frame of the benchmark scene, 16 samples per pixel (33 M paths: one whole sample group, the kernel's
-    steady state with every wave busy), against the CPU checker: every double."""
+    steady state with every wave busy), against the CPU checker: every double; and, where the reference's own build has
+    travelled with the tree (oracle/_ref), against the reference itself."""
+    from oracle.bindings import RefLib, have_ref
     host, device, checker = scenes("chess32")
     frame = host.frame(1920, 1080, sample_count=16, max_bounces=50)
-    assert same_bits(device.render(frame), checker.render(frame, threads=16))
+    got = device.render(frame)
+    assert same_bits(got, checker.render(frame, threads=16))
+    if have_ref():
+        assert same_bits(got, RefLib().scene_create(host.arrays()).render(frame, threads=16))
+
+
+@pytest.mark.parametrize("name, spp", [("chess32", 4), ("mixed", 4), ("grid2", 2)])
+def test_benchmark_scenes_against_the_reference(scenes, benchmark_golden, name, spp):
+    """The benchmark's scenes as the reference's own code rendered them (tests/golden/benchmark_scenes.npz): first-vertex
+    indices and every double of a 160 x 90 frame at the reference's depth, three rows of the 1920 x 1080 frame at 16 samples
+    per pixel by digest."""
+    g = benchmark_golden
+    host, device, _ = scenes(name)
+    assert np.array_equal(sha256_of(host.arrays()["triangles"]), g[f"{name}_triangles_sha"])
+    frame = host.frame(160, 90, sample_count=spp, max_bounces=50)
+    tri, sphere = device.primary_hits(frame)
+    assert np.array_equal(tri, g[f"{name}_tri_hits"]) and np.array_equal(sphere, g[f"{name}_sphere_hits"])
+    assert same_bits(device.render(frame), g[f"{name}_accum"])
+    if name != "grid2":
+        for row in BENCHMARK_ROWS_1080P:
+            big = host.frame(1920, 1080, sample_count=16, max_bounces=50, row_begin=row, row_end=row + 1)
+            got = device.render(big).reshape(1080, 1920, 4)[row]
+            assert np.array_equal(sha256_of(got), g[f"{name}_1080p_row{row}_sha"]), row
 
 
 @pytest.mark.parametrize("name, size, spp, bounces", [

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MODELS, id_hash, same_bits
+from conftest import BENCHMARK_ROWS_1080P, MODELS, id_hash, same_bits, sha256_of
 from pathtracer_amd.ctypes_abi import PtCamera, PtFrame
 
 PIECES = ["pawn", "rook", "knight", "bishop", "queen", "king"]
@@ -155,3 +155,28 @@ def test_oracle_vs_live_reference(orc, ref):
     index_o, dist_o = scene_o.trace_triangles(rays)
     index_r, dist_r = scene_r.trace_triangles(rays)
     assert np.array_equal(index_o, index_r) and same_bits(dist_o, dist_r)
+
+
+@pytest.mark.parametrize("name, param, spp", [("chess32", 0, 4), ("mixed", 0, 4), ("grid2", 2, 2)])
+def test_benchmark_scenes_against_the_reference(orc, api, benchmark_golden, name, param, spp):
+    """The scenes the benchmark renders - the 32-piece chess set, the same with every material, four boards of it - as the
+    reference's own code rendered them (trees, traversal and bounce loop the reference's; fixtures written by
+    oracle/gen_benchmark_golden.py): first-vertex indices and every double of a 160 x 90 frame, and three rows of the
+    1920 x 1080 frame at 16 samples per pixel by digest."""
+    from pathtracer_amd import ctypes_abi as abi
+    g = benchmark_golden
+    kind = {"chess32": abi.PT_SCENE_CHESS32, "mixed": abi.PT_SCENE_CHESS32_MIXED, "grid2": abi.PT_SCENE_CHESS_GRID}[name]
+    host = api.HostScene(kind, MODELS, param)
+    arrays = host.arrays()
+    assert np.array_equal(sha256_of(arrays["triangles"]), g[f"{name}_triangles_sha"])           # the same inputs
+    assert same_bits(np.frombuffer(bytes(host.camera), np.float64), g[f"{name}_camera"])
+    scene = orc.scene_create(arrays)
+    frame = host.frame(160, 90, sample_count=spp, max_bounces=50)
+    tri, sphere = scene.primary_hits(frame)
+    assert np.array_equal(tri, g[f"{name}_tri_hits"]) and np.array_equal(sphere, g[f"{name}_sphere_hits"])
+    assert same_bits(scene.render(frame, threads=8), g[f"{name}_accum"])
+    if name != "grid2":
+        for row in BENCHMARK_ROWS_1080P:
+            big = host.frame(1920, 1080, sample_count=16, max_bounces=50, row_begin=row, row_end=row + 1)
+            got = scene.render(big, threads=8).reshape(1080, 1920, 4)[row]
+            assert np.array_equal(sha256_of(got), g[f"{name}_1080p_row{row}_sha"]), row
