@@ -13,7 +13,7 @@ LIB      := pathtracer_amd/libpathtracer_amd.so
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wextra -Wno-unused-parameter
 HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter $(EXTRA_HIPFLAGS)
 
-HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp $(CSRC)/sah_build.cpp
+HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp $(CSRC)/sah_build.cpp $(CSRC)/presplit.cpp
 HOST_OBJS := $(HOST_SRCS:.cpp=.o)
 HIP_OBJS  := $(CSRC)/pt_gpu.o
 

@@ -236,6 +236,7 @@ struct DeviceBuffer {
 };
 
 constexpr int MAX_DEVICES = 64;
+constexpr double DEFAULT_PRESPLIT = 0.25;
 // What a scene handle may keep of device memory for its per-path colour records unless its owner says otherwise: the
 // benchmark frame (1920 x 1080 x 256 samples, 17 GB) fits; longer sample ranges run in batches (3840 x 2160 x 1024: 11 of them,
 // 4 % slower than through 96 GB).
@@ -406,6 +407,12 @@ int search_height_cap() {
 
 using pt::StageClock;
 
+// References added by cutting large triangles (presplit.cpp), as a fraction of the triangle count (PT_PRESPLIT overrides; 0 = none).
+double presplit_fraction() {
+    if (const char* v = std::getenv("PT_PRESPLIT")) return std::max(0.0, std::atof(v));
+    return DEFAULT_PRESPLIT;
+}
+
 }  // namespace
 
 struct PtScene {
@@ -557,15 +564,50 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     if (d.sphere_count == 1 && !in_range(pt::box_of(d.spheres[0]))) return PT_OK;    // the lone sphere's box is tested by the same kernel
     clock.done("primitive boxes");
 
-    PairNodes merged_pairs;
+    // What the hierarchy is built over: one reference per primitive, and several for large triangles that fill little of
+    // their boxes (presplit.cpp).  Every reference names its primitive, so a search still ends at primitives; only the
+    // boxes it goes through are tighter.  The binary hierarchy `tri_pairs` is over whole triangles and stays what the
+    // exact-node search uses (there a leaf's box in the tree is the reference's own leaf box).
+    PairNodes search_pairs;
     const PairNodes* pairs = &tri_pairs;
-    if (merge) {
-        int root = 0, height = 0;
-        if (pt::build_sah_pairs(own_boxes.data(), static_cast<int>(box_count), search_height_cap(), &merged_pairs, &root, &height) != PT_OK) {
-            pt::clear_error();
-            return PT_OK;
+    pt::UnfilledVector<PtAabb> reference_boxes;
+    std::vector<int32_t> reference_primitive;
+    const double presplit = presplit_fraction();
+    long long cut = 0;
+    if (presplit > 0.0 && triangle_count > 0 && !reference_topology) {
+        cut = pt::presplit_triangles(d.triangles, triangle_count, own_boxes.data(), presplit, &reference_boxes, &reference_primitive);
+        clock.done("large triangles cut into several references");
+    }
+    if (merge || cut > 0) {
+        const PtAabb* boxes = own_boxes.data();
+        long long references = box_count;
+        if (cut > 0) {
+            for (long long i = triangle_count; i < box_count; ++i) {       // the spheres, uncut, behind the triangles' references
+                reference_boxes.push_back(own_boxes[i]);
+                reference_primitive.push_back(static_cast<int32_t>(i));
+            }
+            boxes = reference_boxes.data();
+            references = static_cast<long long>(reference_boxes.size());
         }
-        pairs = &merged_pairs;
+        int root = 0, height = 0;
+        if (pt::build_sah_pairs(boxes, static_cast<int>(references), search_height_cap(), &search_pairs, &root, &height) != PT_OK) {
+            pt::clear_error();
+            if (merge) return PT_OK;
+            cut = 0;                                        // the triangles' own hierarchy serves
+        } else {
+            if (cut > 0) {
+                // leaves name references: put the primitives in their place
+                pt::in_parts(0, static_cast<long long>(search_pairs.size()), search_pairs.size() >= (1u << 16) ? pt::host_threads() : 1, [&](long long from, long long to, int) {
+                    for (long long i = from; i < to; ++i) {
+                        PairNodeHost& p = search_pairs[i];
+                        if (p.left < 0) p.left = ~reference_primitive[~p.left];
+                        if (p.right < 0) p.right = ~reference_primitive[~p.right];
+                    }
+                });
+            }
+            pairs = &search_pairs;
+        }
+        clock.done("search hierarchy over the references built (SAH)");
     }
     if (pairs->empty()) return PT_OK;
     static_assert(sizeof(QuadNode32Host) == sizeof(QuadNode32) && sizeof(QuadBoxes64Host) == sizeof(QuadBoxes64), "host and device four-wide nodes must match");

@@ -44,6 +44,11 @@ int build_sah_pairs(const PtAabb* boxes, int count, int max_height, pt::Unfilled
                     int* height_out);
 
 
+// References for the search hierarchy (presplit.cpp): boxes[i] bounds a part of triangle primitive[i]; large triangles that
+// fill little of their boxes are cut into several references.  Returns how many were added to the `count` uncut ones.
+long long presplit_triangles(const PtTriangle* triangles, long long count, const PtAabb* own_boxes, double extra_fraction,
+                             pt::UnfilledVector<PtAabb>* boxes, std::vector<int32_t>* primitive);
+
 // The binary hierarchy `pairs` (root = pair 0) collapsed to four children per node: a node takes the two
 // children of a pair and then, while a slot is free, replaces its largest inner child by that child's two.
 // Built by several threads; the result does not depend on how many.
