@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
-#include <queue>
 #include <vector>
 
 #include "pt_internal.h"
@@ -73,89 +72,115 @@ Polygon clip(const Polygon& in, int axis, double at, bool keep_low) {
 }
 
 // What a reference's box has beyond the flat piece it bounds: its surface minus the piece's two faces.
-struct Candidate {
-    double excess;
-    int32_t primitive;
-    int32_t pieces_left;       // how many more references this triangle may still be cut into
-    Polygon shape;
-    bool operator<(const Candidate& o) const { return excess < o.excess; }
-};
+double excess_of(const Polygon& p) { return surface(box_of(p)) - 2.0 * area(p); }
 
-}  // namespace
+struct Piece { int32_t primitive; PtAabb box; };
 
-// References for the search hierarchy: `boxes[i]` bounds a part of triangle `primitive[i]`; every triangle has at least
-// one, and the boxes of a triangle's references together contain it.  At most `extra_fraction` * count references are
-// added to the `count` there are without cutting.  Returns the number of references added.
-long long presplit_triangles(const PtTriangle* triangles, long long count, const PtAabb* own_boxes, double extra_fraction,
-                             UnfilledVector<PtAabb>* boxes, std::vector<int32_t>* primitive) {
-    boxes->resize(count);
-    primitive->resize(count);
-    double total = 0.0;
-    for (long long i = 0; i < count; ++i) {
-        (*boxes)[i] = own_boxes[i];
-        (*primitive)[i] = static_cast<int32_t>(i);
-        const double s = surface(own_boxes[i]);
-        if (std::isfinite(s)) total += s;
-    }
-    const long long budget = static_cast<long long>(extra_fraction * static_cast<double>(count));
-    if (budget <= 0 || count == 0 || !(total > 0.0)) return 0;
-    // worth cutting: boxes with more spare surface than a typical box has surface at all
-    double floor_factor = 2.0;
-    if (const char* v = std::getenv("PT_PRESPLIT_FLOOR")) floor_factor = std::atof(v);
-    const double floor_excess = floor_factor * total / static_cast<double>(count);
-    std::priority_queue<Candidate> queue;
-    for (long long i = 0; i < count; ++i) {
-        const PtTriangle& t = triangles[i];
-        Polygon p;
-        p.n = 3;
-        p.v[0] = P3{t.a.x, t.a.y, t.a.z}; p.v[1] = P3{t.b.x, t.b.y, t.b.z}; p.v[2] = P3{t.c.x, t.c.y, t.c.z};
-        const double excess = surface(own_boxes[i]) - 2.0 * area(p);
-        if (excess > floor_excess && std::isfinite(excess)) queue.push(Candidate{excess, static_cast<int32_t>(i), 63, p});
-    }
-    // A triangle's first reference keeps the triangle's place in the arrays (and is narrowed in place); later pieces are appended.
-    std::vector<char> placed(static_cast<size_t>(count), 0);
-    long long added = 0;
-    std::vector<Candidate> finished;
-    while (!queue.empty()) {
-        Candidate c = queue.top();
-        queue.pop();
-        const PtAabb b = box_of(c.shape);
+// The references of one triangle: the triangle is halved at the middle of its box's longest axis while a piece's box has
+// more than `floor_excess` of spare surface, into at most MAX_PIECES pieces.  The first piece goes to *first, the rest
+// are appended to *more.  Returns the number of pieces.
+constexpr int MAX_PIECES = 64;
+int cut_triangle(const PtTriangle& t, int32_t primitive, const PtAabb& own, double floor_excess, PtAabb* first, std::vector<Piece>* more) {
+    struct Work { Polygon shape; int pieces; };     // `pieces`: how many references this part may still become
+    Work stack[2 * MAX_PIECES];
+    int top = 0, made = 0;
+    stack[top].shape.n = 3;
+    stack[top].shape.v[0] = P3{t.a.x, t.a.y, t.a.z}; stack[top].shape.v[1] = P3{t.b.x, t.b.y, t.b.z}; stack[top].shape.v[2] = P3{t.c.x, t.c.y, t.c.z};
+    stack[top++].pieces = MAX_PIECES;
+    while (top > 0) {
+        const Work w = stack[--top];
+        const PtAabb b = box_of(w.shape);
         const double ex = b.max.x - b.min.x, ey = b.max.y - b.min.y, ez = b.max.z - b.min.z;
         const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
         const double lo = axis == 0 ? b.min.x : (axis == 1 ? b.min.y : b.min.z), hi = axis == 0 ? b.max.x : (axis == 1 ? b.max.y : b.max.z);
         const double at = 0.5 * (lo + hi);
-        bool cut = added < budget && c.pieces_left > 0 && c.excess > floor_excess && at > lo && at < hi;
+        bool cut = w.pieces >= 2 && at > lo && at < hi && excess_of(w.shape) > floor_excess;
         Polygon low, high;
         if (cut) {
-            low = clip(c.shape, axis, at, true);
-            high = clip(c.shape, axis, at, false);
+            low = clip(w.shape, axis, at, true);
+            high = clip(w.shape, axis, at, false);
             cut = low.n >= 3 && high.n >= 3;
         }
-        if (!cut) {
-            finished.push_back(c);
+        if (cut) {
+            stack[top++] = Work{high, w.pieces - w.pieces / 2};
+            stack[top++] = Work{low, w.pieces / 2};
             continue;
         }
-        ++added;
-        const int32_t share = c.pieces_left - 1;
-        queue.push(Candidate{surface(box_of(low)) - 2.0 * area(low), c.primitive, share / 2, low});
-        queue.push(Candidate{surface(box_of(high)) - 2.0 * area(high), c.primitive, share - share / 2, high});
-    }
-    for (const Candidate& c : finished) {
-        PtAabb b = box_of(c.shape);
+        PtAabb piece = b;
         // the cut points are rounded: a margin far above that rounding, far below anything that would cost visits
         const double mx = 1e-9 * (std::fabs(b.min.x) + std::fabs(b.max.x)) + 1e-30, my = 1e-9 * (std::fabs(b.min.y) + std::fabs(b.max.y)) + 1e-30,
                      mz = 1e-9 * (std::fabs(b.min.z) + std::fabs(b.max.z)) + 1e-30;
-        b.min.x -= mx; b.min.y -= my; b.min.z -= mz; b.max.x += mx; b.max.y += my; b.max.z += mz;
+        piece.min.x -= mx; piece.min.y -= my; piece.min.z -= mz; piece.max.x += mx; piece.max.y += my; piece.max.z += mz;
         // never beyond the triangle's own box: that one is exact
-        const PtAabb& own = own_boxes[c.primitive];
-        b.min.x = std::max(b.min.x, own.min.x); b.min.y = std::max(b.min.y, own.min.y); b.min.z = std::max(b.min.z, own.min.z);
-        b.max.x = std::min(b.max.x, own.max.x); b.max.y = std::min(b.max.y, own.max.y); b.max.z = std::min(b.max.z, own.max.z);
-        if (!placed[c.primitive]) {
-            placed[c.primitive] = 1;
-            (*boxes)[c.primitive] = b;
-        } else {
-            boxes->push_back(b);
-            primitive->push_back(c.primitive);
+        piece.min.x = std::max(piece.min.x, own.min.x); piece.min.y = std::max(piece.min.y, own.min.y); piece.min.z = std::max(piece.min.z, own.min.z);
+        piece.max.x = std::min(piece.max.x, own.max.x); piece.max.y = std::min(piece.max.y, own.max.y); piece.max.z = std::min(piece.max.z, own.max.z);
+        if (made++ == 0) *first = piece;
+        else more->push_back(Piece{primitive, piece});
+    }
+    return made;
+}
+
+}  // namespace
+
+// References for the search hierarchy: `boxes[i]` bounds a part of triangle `primitive[i]`; every triangle has at least
+// one (reference i < count belongs to triangle i; the pieces beyond a triangle's first follow, by triangle), and the boxes
+// of a triangle's references together contain it.  A piece is cut while its box has more spare surface than
+// `floor_factor` times the mean surface of all triangles' boxes; if that adds more than `extra_fraction` * count
+// references, the bar is raised until it does not.  The result does not depend on the number of threads.
+// Returns the number of references added.
+long long presplit_triangles(const PtTriangle* triangles, long long count, const PtAabb* own_boxes, double floor_factor, double extra_fraction,
+                             UnfilledVector<PtAabb>* boxes, std::vector<int32_t>* primitive) {
+    boxes->resize(count);
+    primitive->resize(count);
+    if (count == 0) return 0;
+    const int team = count >= (1 << 16) ? host_threads() : 1;
+    std::vector<double> sums(team, 0.0);
+    in_parts(0, count, team, [&](long long from, long long to, int part) {
+        double sum = 0.0;
+        for (long long i = from; i < to; ++i) {
+            const double s = surface(own_boxes[i]);
+            if (std::isfinite(s)) sum += s;
+        }
+        sums[part] = sum;
+    });
+    // summed in units of fixed size, so that the bar below (and with it every cut) is the same for any number of threads
+    double total = 0.0;
+    if (team > 1) {
+        total = 0.0;
+        for (long long i = 0; i < count; ++i) { const double s = surface(own_boxes[i]); if (std::isfinite(s)) total += s; }
+    } else {
+        total = sums[0];
+    }
+    const long long budget = static_cast<long long>(extra_fraction * static_cast<double>(count));
+    if (budget <= 0 || !(total > 0.0) || !(floor_factor > 0.0)) {
+        for (long long i = 0; i < count; ++i) { (*boxes)[i] = own_boxes[i]; (*primitive)[i] = static_cast<int32_t>(i); }
+        return 0;
+    }
+    double floor_excess = floor_factor * total / static_cast<double>(count);
+    std::vector<std::vector<Piece>> more(team);
+    for (;;) {
+        in_parts(0, count, team, [&](long long from, long long to, int part) {
+            std::vector<Piece>& mine = more[part];
+            mine.clear();
+            for (long long i = from; i < to; ++i) {
+                (*boxes)[i] = own_boxes[i];
+                (*primitive)[i] = static_cast<int32_t>(i);
+                const double s = surface(own_boxes[i]);
+                if (!(s > floor_excess) || !std::isfinite(s)) continue;        // the spare surface is less than the surface
+                cut_triangle(triangles[i], static_cast<int32_t>(i), own_boxes[i], floor_excess, &(*boxes)[i], &mine);
+            }
+        });
+        long long added = 0;
+        for (const std::vector<Piece>& m : more) added += static_cast<long long>(m.size());
+        if (added <= budget) break;
+        floor_excess *= 2.0;
+    }
+    long long added = 0;
+    for (const std::vector<Piece>& m : more) {          // in the order of the parts: by triangle, whatever the number of threads
+        for (const Piece& p : m) {
+            boxes->push_back(p.box);
+            primitive->push_back(p.primitive);
+            ++added;
         }
     }
     return added;

@@ -236,7 +236,7 @@ struct DeviceBuffer {
 };
 
 constexpr int MAX_DEVICES = 64;
-constexpr double DEFAULT_PRESPLIT = 0.25;
+constexpr double DEFAULT_PRESPLIT = 1.5, DEFAULT_PRESPLIT_FLOOR = 0.2;
 // What a scene handle may keep of device memory for its per-path colour records unless its owner says otherwise: the
 // benchmark frame (1920 x 1080 x 256 samples, 17 GB) fits; longer sample ranges run in batches (3840 x 2160 x 1024: 11 of them,
 // 4 % slower than through 96 GB).
@@ -407,7 +407,13 @@ int search_height_cap() {
 
 using pt::StageClock;
 
-// References added by cutting large triangles (presplit.cpp), as a fraction of the triangle count (PT_PRESPLIT overrides; 0 = none).
+// Cutting large triangles into several references (presplit.cpp): a piece is cut while its box has more spare surface than
+// this many mean box surfaces (PT_PRESPLIT_FLOOR overrides), for at most this fraction of the triangle count in added
+// references (PT_PRESPLIT overrides; 0 = no cutting).
+double presplit_floor() {
+    if (const char* v = std::getenv("PT_PRESPLIT_FLOOR")) return std::max(0.0, std::atof(v));
+    return DEFAULT_PRESPLIT_FLOOR;
+}
 double presplit_fraction() {
     if (const char* v = std::getenv("PT_PRESPLIT")) return std::max(0.0, std::atof(v));
     return DEFAULT_PRESPLIT;
@@ -572,10 +578,12 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     const PairNodes* pairs = &tri_pairs;
     pt::UnfilledVector<PtAabb> reference_boxes;
     std::vector<int32_t> reference_primitive;
-    const double presplit = presplit_fraction();
+    // (at most four million added references where that is less: a scene of ten million triangles is bound by memory, and more
+    // nodes cost it what fewer triangle tests gain)
+    const double presplit = std::min(presplit_fraction(), std::max(0.25, 4.0e6 / static_cast<double>(std::max<long long>(1, triangle_count))));
     long long cut = 0;
     if (presplit > 0.0 && triangle_count > 0 && !reference_topology) {
-        cut = pt::presplit_triangles(d.triangles, triangle_count, own_boxes.data(), presplit, &reference_boxes, &reference_primitive);
+        cut = pt::presplit_triangles(d.triangles, triangle_count, own_boxes.data(), presplit_floor(), presplit, &reference_boxes, &reference_primitive);
         clock.done("large triangles cut into several references");
     }
     if (merge || cut > 0) {
@@ -698,8 +706,8 @@ struct Tunables {
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
-    int shade_threshold = 36;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams (swept: profiles/r2/threshold_sweep.log)
-    int leaf_threshold = 20;
+    int shade_threshold = 40;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams (swept: profiles/r3/thresholds_presplit.log)
+    int leaf_threshold = 16;
     int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
     int distrust_mask = -1;             // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winner to the fallback)
     Tunables() {

@@ -46,7 +46,7 @@ int build_sah_pairs(const PtAabb* boxes, int count, int max_height, pt::Unfilled
 
 // References for the search hierarchy (presplit.cpp): boxes[i] bounds a part of triangle primitive[i]; large triangles that
 // fill little of their boxes are cut into several references.  Returns how many were added to the `count` uncut ones.
-long long presplit_triangles(const PtTriangle* triangles, long long count, const PtAabb* own_boxes, double extra_fraction,
+long long presplit_triangles(const PtTriangle* triangles, long long count, const PtAabb* own_boxes, double floor_factor, double extra_fraction,
                              pt::UnfilledVector<PtAabb>* boxes, std::vector<int32_t>* primitive);
 
 // The binary hierarchy `pairs` (root = pair 0) collapsed to four children per node: a node takes the two
