@@ -237,6 +237,7 @@ struct DeviceBuffer {
 
 constexpr int MAX_DEVICES = 64;
 constexpr double DEFAULT_PRESPLIT = 1.5, DEFAULT_PRESPLIT_FLOOR = 0.2;
+constexpr long long PRESPLIT_LEAST_TRIANGLES = 4096;
 // What a scene handle may keep of device memory for its per-path colour records unless its owner says otherwise: the
 // benchmark frame (1920 x 1080 x 256 samples, 17 GB) fits; longer sample ranges run in batches (3840 x 2160 x 1024: 11 of them,
 // 4 % slower than through 96 GB).
@@ -582,7 +583,9 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     // nodes cost it what fewer triangle tests gain)
     const double presplit = std::min(presplit_fraction(), std::max(0.25, 4.0e6 / static_cast<double>(std::max<long long>(1, triangle_count))));
     long long cut = 0;
-    if (presplit > 0.0 && triangle_count > 0 && !reference_topology) {
+    // (not in a scene of a few triangles: there every level the hierarchy gains is a node step for almost every ray, and the
+    // Cornell box's 36 wall triangles cut up cost it 16 %)
+    if (presplit > 0.0 && triangle_count >= PRESPLIT_LEAST_TRIANGLES && !reference_topology) {
         cut = pt::presplit_triangles(d.triangles, triangle_count, own_boxes.data(), presplit_floor(), presplit, &reference_boxes, &reference_primitive);
         clock.done("large triangles cut into several references");
     }
