@@ -26,9 +26,6 @@
 
 namespace ptd {
 
-#ifndef PT_PREFETCH
-#define PT_PREFETCH 0
-#endif
 #ifndef PT_SAMPLES_PER_CHUNK
 #define PT_SAMPLES_PER_CHUNK 16
 #endif
@@ -93,9 +90,6 @@ struct WaveStats {   // wave-uniform counters of a profiling build
 struct WaveShared {
     TourFrame frames[(BLOCK_THREADS / 64) * (STACK_DEPTH + 1)];
     double pool[BLOCK_THREADS / 64][6][64];     // per wave: the camera rays of the next 64 paths (origin, direction)
-#if PT_PREFETCH
-    int prefetched[BLOCK_THREADS / 64][64];     // where the prefetching loads of the node step land; never read
-#endif
 };
 
 // STATS: 0 = none; 1 = phase/lane counters and the f32-versus-f64 box-test cross-check; 2 = the
@@ -104,12 +98,6 @@ struct WaveShared {
 // NODE32: inner nodes are the 128-byte single-precision nodes with four children (conservative
 // test; the exact test of the winning primitive's own box is made before the path is shaded);
 // otherwise the 128-byte double-precision pairs, whose test is the reference's own.
-#ifndef PT_NODE_REPEAT
-#define PT_NODE_REPEAT 0
-#endif
-#ifndef PT_NODE_REPEAT_LANES
-#define PT_NODE_REPEAT_LANES 24
-#endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 3
 #endif
@@ -216,18 +204,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
         sp = top;
         cur = next;
-#if PT_PREFETCH
-        {
-            // One word of the record the lane visits next, asked for now, so that its line is on its way while the wave
-            // chooses a phase.  The load writes LDS (a word per lane that nothing reads): no register waits for it.
-            const char* line = (next >= 0 || PT_PREFETCH < 2) ? reinterpret_cast<const char*>(s.tri_quads) + ((size_t)(unsigned)max(next, 0) << 7)
-                                                              : reinterpret_cast<const char*>(s.tris) + ((size_t)(unsigned)~next << 7);
-            if (st != ST_SHADE) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)line,
-                                                 (__attribute__((address_space(3))) void*)&sh.prefetched[threadIdx.x >> 6][0], 4, 0, 0);
-            }
-        }
-#endif
     };
 
     for (;;) {
@@ -487,15 +463,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             if (STATS == 2) t0 = clock64();
             // Straight-line code: all four children are written to the stack, skipped ones above its new top
             // (the launch sizes the stack for it), and every decision is a select.
-            if (NODE32 && PT_NODE_REPEAT > 0) {
-                // The node step again, without going through the choice of a phase, while that choice would come out the same.
-                for (int again = 0; again < PT_NODE_REPEAT; ++again) {
-                    const int nodes = __popcll(__ballot(st == ST_NODE)), leaves = __popcll(__ballot(st == ST_LEAF));
-                    if (nodes < PT_NODE_REPEAT_LANES || leaves >= w.leaf_threshold || 64 - nodes - leaves >= w.shade_threshold) break;
-                    if (STATS) { ++ws.node_phases; ws.node_lanes += nodes; }
-                    if (st == ST_NODE) quad_step(cur);
-                }
-            }
             if (STATS) { ++ws.node_phases; ws.node_lanes += __popcll(__ballot(st == ST_NODE)); }
             if (st == ST_NODE) {
                 if (NODE32) {
