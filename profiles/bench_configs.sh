@@ -1,6 +1,6 @@
 #!/bin/bash
-# bench.py on the headline workload and the other configurations (one GPU); lines under gpurun_out/r2/configs/.
-out=gpurun_out/r2/configs; mkdir -p $out
+# bench.py on the headline workload and the other configurations (one GPU); lines under gpurun_out/${ROUND:-r3}/configs/.
+out=gpurun_out/${ROUND:-r3}/configs; mkdir -p $out
 run() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > $out/$name.json 2> $out/$name.err || { echo "$name failed"; tail -3 $out/$name.err; exit 1; }; python3 -c "
 import json, sys
 d = json.loads(open('$out/$name.json').read().strip().splitlines()[-1])

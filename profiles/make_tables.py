@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of profiles/profile_workload.sh (gpurun_out/r2/<name>/) into the tables bench.py reads:
-profiles/executed_work.json, profiles/hbm_traffic.json, and a summary per workload under profiles/r2/<name>/.
+"""Turns the rocprofv3 outputs of profiles/profile_workload.sh (gpurun_out/$ROUND/<name>/) into the tables bench.py reads:
+profiles/executed_work.json, profiles/hbm_traffic.json, and a summary per workload under profiles/$ROUND/<name>/ (ROUND defaults to r3).
 usage: python profiles/make_tables.py name:scene:WxH:spp:bounces ..."""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = os.environ.get("ROUND", "r3")
 
 
 def counters(directory, kernel):
@@ -24,8 +25,8 @@ def main():
     for spec in sys.argv[1:]:
         name, scene, size, spp, bounces = spec.split(":")
         w, h = (int(v) for v in size.split("x"))
-        src = os.path.join(ROOT, "gpurun_out", "r2", name)
-        dst = os.path.join(ROOT, "profiles", "r2", name)
+        src = os.path.join(ROOT, "gpurun_out", ROUND, name)
+        dst = os.path.join(ROOT, "profiles", ROUND, name)
         os.makedirs(dst, exist_ok=True)
         key = f"{scene} {w}x{h} {spp}spp depth{bounces}"
         paths = w * h * int(spp)
@@ -53,7 +54,7 @@ def main():
         if kernel_ms:
             summary["hbm_GBps"] = hbm / kernel_ms / 1e6
         json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-        source = f"profiles/r2/{name}/pmc_summary.json (rocprofv3 --pmc, one pass per counter group, python3 profiles/stats_run.py {spp} {scene} {bounces}, PT_SIZE={size}, mean of two launches)"
+        source = f"profiles/{ROUND}/{name}/pmc_summary.json (rocprofv3 --pmc, one pass per counter group, python3 profiles/stats_run.py {spp} {scene} {bounces}, PT_SIZE={size}, mean of two launches)"
         work[key] = {"valu_wave_instructions_per_path": trace["SQ_INSTS_VALU"] / paths, "salu_per_path": trace["SQ_INSTS_SALU"] / paths,
                      "vmem_read_per_path": trace["SQ_INSTS_VMEM_RD"] / paths, "l1_accesses_per_path": trace.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / paths,
                      "source": source}

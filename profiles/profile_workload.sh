@@ -1,10 +1,10 @@
 #!/bin/bash
 # Kernel trace and counter passes of one workload per call:
 #   profiles/profile_workload.sh <name> <scene> <WxH> <spp> <bounces>
-# kernel trace + stats, then counter passes (each its own rocprofv3 run), all under gpurun_out/r2/<name>/.
+# kernel trace + stats, then counter passes (each its own rocprofv3 run), all under gpurun_out/$ROUND/<name>/ (ROUND defaults to r3).
 export TMPDIR=/tmp
 name=$1; scene=$2; size=$3; spp=$4; bounces=$5
-out=gpurun_out/r2/$name
+out=gpurun_out/${ROUND:-r3}/$name
 mkdir -p $out
 export PT_SIZE=$size ITERATIONS=2
 prog="python3 profiles/stats_run.py $spp $scene $bounces"
