@@ -138,22 +138,11 @@ long long presplit_triangles(const PtTriangle* triangles, long long count, const
     primitive->resize(count);
     if (count == 0) return 0;
     const int team = count >= (1 << 16) ? host_threads() : 1;
-    std::vector<double> sums(team, 0.0);
-    in_parts(0, count, team, [&](long long from, long long to, int part) {
-        double sum = 0.0;
-        for (long long i = from; i < to; ++i) {
-            const double s = surface(own_boxes[i]);
-            if (std::isfinite(s)) sum += s;
-        }
-        sums[part] = sum;
-    });
-    // summed in units of fixed size, so that the bar below (and with it every cut) is the same for any number of threads
+    // summed in one fixed order, so that the bar below (and with it every cut) is the same for any number of threads
     double total = 0.0;
-    if (team > 1) {
-        total = 0.0;
-        for (long long i = 0; i < count; ++i) { const double s = surface(own_boxes[i]); if (std::isfinite(s)) total += s; }
-    } else {
-        total = sums[0];
+    for (long long i = 0; i < count; ++i) {
+        const double s = surface(own_boxes[i]);
+        if (std::isfinite(s)) total += s;
     }
     const long long budget = static_cast<long long>(extra_fraction * static_cast<double>(count));
     if (budget <= 0 || !(total > 0.0) || !(floor_factor > 0.0)) {

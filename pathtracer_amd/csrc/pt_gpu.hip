@@ -628,8 +628,8 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     if (quads.nodes.size() > (size_t(1) << 25)) return PT_OK;   // the kernel addresses a node by a 32-bit byte offset
     scene->tri_stack_need = quads.deepest_pending + 4;      // a visit writes four slots above the pending entries
     if (std::getenv("PT_VERBOSE") != nullptr) {
-        std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n", own_boxes.size(),
-                     merge ? " (triangles and spheres in one hierarchy)" : "", pairs->size(), quads.nodes.size(), scene->tri_stack_need);
+        std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %lld references more for large triangles, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n",
+                     own_boxes.size(), merge ? " (triangles and spheres in one hierarchy)" : "", cut, pairs->size(), quads.nodes.size(), scene->tri_stack_need);
     }
     static_assert(sizeof(LeafBox) == sizeof(PtAabb), "a leaf box on the device is the six doubles of PtAabb: min x, y, z, max x, y, z");
     int rc = up.send(scene->tri_quads, quads.nodes.data(), quads.nodes.size() * sizeof(QuadNode32));
