@@ -240,7 +240,7 @@ constexpr double DEFAULT_PRESPLIT = 1.5, DEFAULT_PRESPLIT_FLOOR = 0.2;
 constexpr long long PRESPLIT_LEAST_TRIANGLES = 4096;
 // What a scene handle may keep of device memory for its per-path colour records unless its owner says otherwise: the
 // benchmark frame (1920 x 1080 x 256 samples, 17 GB) fits; longer sample ranges run in batches (3840 x 2160 x 1024: 11 of them,
-// 4 % slower than through 96 GB).
+// 2 % slower than in 3 through 96 GB).
 constexpr size_t DEFAULT_WORKSPACE_BYTES = size_t(24) << 30;
 std::mutex static_scratch_lock;
 void* static_scratch_address[MAX_DEVICES] = {};     // per device, resolved once with that device current
@@ -419,6 +419,11 @@ double presplit_fraction() {
     if (const char* v = std::getenv("PT_PRESPLIT")) return std::max(0.0, std::atof(v));
     return DEFAULT_PRESPLIT;
 }
+// Scenes of fewer triangles than this are not cut (PT_PRESPLIT_LEAST overrides: the tests cut scenes of a few triangles).
+long long presplit_least_triangles() {
+    if (const char* v = std::getenv("PT_PRESPLIT_LEAST")) return std::max(0ll, std::atoll(v));
+    return PRESPLIT_LEAST_TRIANGLES;
+}
 
 }  // namespace
 
@@ -585,7 +590,7 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     long long cut = 0;
     // (not in a scene of a few triangles: there every level the hierarchy gains is a node step for almost every ray, and the
     // Cornell box's 36 wall triangles cut up cost it 16 %)
-    if (presplit > 0.0 && triangle_count >= PRESPLIT_LEAST_TRIANGLES && !reference_topology) {
+    if (presplit > 0.0 && triangle_count >= presplit_least_triangles() && !reference_topology) {
         cut = pt::presplit_triangles(d.triangles, triangle_count, own_boxes.data(), presplit_floor(), presplit, &reference_boxes, &reference_primitive);
         clock.done("large triangles cut into several references");
     }

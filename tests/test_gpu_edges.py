@@ -164,6 +164,25 @@ def test_random_scenes_against_the_checker(api, orc, seed):
     _compare(api, orc, arrays, how["eye"], how["target"], size=how["size"], spp=how["spp"], bounces=how["bounces"], aperture=how["aperture"])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_RANDOM_CUT_SCENES", "24"))))
+def test_random_scenes_with_every_triangle_cut_up(api, orc, seed, monkeypatch, capfd):
+    """The same random scenes with the search hierarchy built over *pieces* of the triangles (the library cuts large triangles
+    that fill little of their boxes into several references; by default only in scenes of thousands of triangles): here
+    every scene is cut, far finer than the default bar would, lattice ties, duplicates, degenerate, huge and infinite
+    triangles included.  Primary hit indices and buffers, bit for bit.  PT_RANDOM_CUT_SCENES=<n> widens the campaign."""
+    monkeypatch.setenv("PT_PRESPLIT_LEAST", "1")
+    monkeypatch.setenv("PT_PRESPLIT_FLOOR", ["0.02", "0.2", "0.002"][seed % 3])
+    monkeypatch.setenv("PT_PRESPLIT", ["8", "1.5", "30"][seed % 3])
+    monkeypatch.setenv("PT_VERBOSE", "1")
+    arrays, how, _ = random_scene(api, seed)
+    _compare(api, orc, arrays, how["eye"], how["target"], size=how["size"], spp=how["spp"], bounces=how["bounces"], aperture=how["aperture"])
+    import re
+    added = [int(n) for n in re.findall(r"(\d+) references more", capfd.readouterr().err)]
+    print("seed", seed, "triangles", len(arrays["triangles"]), "references added", added)
+    if seed in (2, 8, 14, 17):
+        assert added and max(added) > 0, "this scene's triangles should have been cut"
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PT_RANDOM_FRAMES", "12"))))
 def test_random_frames_against_the_checker(api, orc, seed):
     """Seeded random *frames* over a small random scene: odd sizes, row ranges that start anywhere, shards, sample ranges that
