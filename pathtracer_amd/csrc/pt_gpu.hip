@@ -438,8 +438,8 @@ struct PtScene {
     hipStream_t last_stream = nullptr;
     bool timed = false;
     // wavefront kernel: per-path colours, the chunk counter and the profiling counters
-    DeviceBuffer rgb, counters;
-    size_t rgb_bytes = 0;
+    DeviceBuffer rgb, counters, park;   // (park: backing store of the lanes' stacks, see WorkParams::parking)
+    size_t rgb_bytes = 0, park_bytes = 0;
     size_t workspace_limit = DEFAULT_WORKSPACE_BYTES;   // cap of `rgb` (pt_scene_set_workspace_limit)
     void* last_counters = nullptr;      // counters of the most recent wavefront launch (the scene's own or the static workspace's)
     void* static_workspace = nullptr;   // this device's copy of the static workspace (pt_render_device_noalloc)
@@ -659,7 +659,7 @@ int check_frame(const PtFrame* f) {
     if ((long long)f->width * f->height > (1ll << 31) / 4) return pt::fail(PT_ERR_INVALID_ARGUMENT, "frame %dx%d is too large", f->width, f->height);
     if (f->row_begin < 0 || f->row_end > f->height || f->row_begin > f->row_end) return pt::fail(PT_ERR_INVALID_ARGUMENT, "row range [%d, %d) is outside the %d-row image", f->row_begin, f->row_end, f->height);
     if (f->sample_begin < 0 || f->sample_count < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "sample range must be non-negative");
-    if (f->max_bounces < 0) return pt::fail(PT_ERR_INVALID_ARGUMENT, "max_bounces must be non-negative");
+    if (f->max_bounces < 0 || f->max_bounces >= (1 << 24)) return pt::fail(PT_ERR_INVALID_ARGUMENT, "max_bounces must be non-negative and below 2^24");
     if (f->shard_count > 1 && (f->shard_index < 0 || f->shard_index >= f->shard_count)) return pt::fail(PT_ERR_INVALID_ARGUMENT, "shard %d of %d does not exist", f->shard_index, f->shard_count);
     return PT_OK;
 }
@@ -718,7 +718,9 @@ struct Tunables {
     int leaf_threshold = 16;
     int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
     int distrust_mask = -1;             // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winner to the fallback)
+    bool parking = true;                // PT_PARKING=0: no backing store for the lanes' stacks (a full stack ends the ordered search)
     Tunables() {
+        if (const char* v = std::getenv("PT_PARKING")) parking = std::atoi(v) != 0;
         if (const char* v = std::getenv("PT_NODES")) force_f64_nodes = std::strcmp(v, "f64") == 0;
         if (const char* v = std::getenv("PT_BVH")) reference_topology = std::strcmp(v, "reference") == 0;
         if (const char* v = std::getenv("PT_STACK_SLOTS")) stack_slots = std::atoi(v);
@@ -746,6 +748,7 @@ struct TraceOutputs {
     unsigned long long* stats = nullptr;
     int* hit_triangle = nullptr;     // both null unless the launch reports first-vertex indices
     int* hit_sphere = nullptr;
+    int* park = nullptr;             // backing store of the lanes' stacks (WorkParams::parking)
 };
 
 template <int STATS, bool NODE32, bool MERGED>
@@ -757,7 +760,7 @@ int launch_trace_paths(unsigned blocks, size_t stack_bytes, hipStream_t stream, 
         return PT_OK;
     }
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(BLOCK_THREADS), stack_bytes, stream,
-                       TraceArgs{dev, fp, wp, out.rgb, out.counter, out.stats, out.hit_triangle, out.hit_sphere});
+                       TraceArgs{dev, fp, wp, out.rgb, out.counter, out.stats, out.hit_triangle, out.hit_sphere, out.park});
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -839,9 +842,15 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
     // per-lane stack slots: the triangle search's need, and the sphere tree's when it is walked in place
     // (a lane of the 4-wide search that would outgrow its slots falls back to the exhaustive traversal, so
     // any number >= 3 is correct there; the binary search and the sphere tree need their full height)
-    const int quad_slots = std::max(4, t.stack_slots > 0 ? std::min(t.stack_slots, scene->tri_stack_need) : scene->tri_stack_need);
+    // A launch that may allocate gives the four-wide search a backing store in device memory for the oldest entries of a
+    // full stack; 24 slots per lane in LDS then serve any depth, and four blocks fit a CU.  One that may not allocate
+    // gives it up to 36 slots (three blocks per CU when a scene needs more than 24) and no backing store.
+    const bool may_park = node32 && !ws.fixed && t.parking;
+    const int quad_slots = std::max(4, std::min(t.stack_slots > 0 ? t.stack_slots : static_cast<int>(may_park ? QUAD_STACK_SLOTS : MAX_WF_STACK_SLOTS),
+                                                scene->tri_stack_need));
     const int stack_slots = std::min(std::max(std::max(node32 ? quad_slots : scene->tri_height, scene->sph_height), 4),
                                      static_cast<int>(MAX_WF_STACK_SLOTS));
+    bool parking = may_park && scene->tri_stack_need > stack_slots && stack_slots >= PARK_UNIT + 4;
     const size_t stack_bytes = static_cast<size_t>(stack_slots) * BLOCK_THREADS * sizeof(int);
     const int variant = 4 * stack_slots + 2 * (t.stats & 1) + (node32 ? 1 : 0) + 1024 * (t.stats >> 1);
     if (scene->compute_units == 0 || scene->occupancy_variant != variant || t.blocks_per_cu > 0) {
@@ -853,6 +862,21 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         const int rc = trace_paths(t.stats, node32, 0, stack_bytes, stream, scene->dev, FrameParams{}, WorkParams{}, TraceOutputs{}, &per_cu);
         if (rc != PT_OK) return rc;
         scene->blocks_per_cu = t.blocks_per_cu > 0 ? t.blocks_per_cu : std::max(1, per_cu);
+    }
+    if (parking) {
+        // a search never has more entries pending than the hierarchy's deepest need, so never more parked units than this
+        const size_t units = (static_cast<size_t>(scene->tri_stack_need) + PARK_UNIT - 1) / PARK_UNIT;
+        const size_t bytes = units * PARK_UNIT * sizeof(int) * BLOCK_THREADS * static_cast<size_t>(scene->compute_units) * static_cast<size_t>(scene->blocks_per_cu);
+        if (scene->park_bytes < bytes) {
+            if (scene->park.p != nullptr) { HIP_TRY(hipFree(scene->park.p)); scene->park.p = nullptr; scene->park_bytes = 0; }
+            if (hipMalloc(&scene->park.p, bytes) == hipSuccess) {
+                scene->park_bytes = bytes;
+            } else {
+                (void)hipGetLastError();
+                scene->park.p = nullptr;
+                parking = false;            // full stacks end their ordered searches instead: the same bytes, slower
+            }
+        }
     }
     unsigned int* counter = static_cast<unsigned int*>(ws.counters);
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(static_cast<char*>(ws.counters) + 512);
@@ -875,6 +899,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         wp.shade_threshold = t.shade_threshold;
         wp.leaf_threshold = t.leaf_threshold;
         wp.stack_slots = stack_slots;
+        wp.parking = parking ? 1 : 0;
         wp.distrust_mask = t.distrust_mask;
         wp.export_hits = ws.hit_triangle != nullptr ? 1 : 0;
         if (!first) HIP_TRY(hipMemsetAsync(counter, 0, 512, stream));
@@ -882,7 +907,7 @@ int launch_wavefront(PtScene* scene, const PtFrame* frame, double* accum_device,
         const unsigned blocks = static_cast<unsigned>(std::min<long long>(static_cast<long long>(scene->compute_units) * scene->blocks_per_cu,
                                                                           (units + 3) / 4));
         const int rc = trace_paths(t.stats, node32, blocks, stack_bytes, stream, scene->dev, fp, wp,
-                                   TraceOutputs{ws.rgb, counter, stats, ws.hit_triangle, ws.hit_sphere}, nullptr);
+                                   TraceOutputs{ws.rgb, counter, stats, ws.hit_triangle, ws.hit_sphere, parking ? static_cast<int*>(scene->park.p) : nullptr}, nullptr);
         if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(sum_samples_kernel, dim3(grid_blocks(*frame)), dim3(BLOCK_THREADS), 0, stream,
                            fp, wp, static_cast<const double*>(ws.rgb), accum_device);

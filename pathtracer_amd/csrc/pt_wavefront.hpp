@@ -33,6 +33,10 @@ constexpr int SAMPLES_PER_CHUNK = PT_SAMPLES_PER_CHUNK;
 constexpr int CHUNK_PATHS = 64 * SAMPLES_PER_CHUNK;
 constexpr int MAX_SEARCH_HEIGHT = 32;  // levels the rebuilt binary hierarchy is kept to (= STACK_DEPTH: a height cap near the minimum forces balanced splits and costs large scenes a third of their speed)
 constexpr int MAX_WF_STACK_SLOTS = 36; // per-lane stack slots a block is given at most (1 KB of LDS each): three blocks per CU still fit
+constexpr int QUAD_STACK_SLOTS = 24;   // what the search through four-wide nodes is given when the launch has a backing store for
+                                       // its stacks: four blocks per CU fit
+constexpr int PARK_UNIT = 12;          // entries a lane whose stack is full moves to the backing store at a time (the oldest ones)
+constexpr int PARKED_SHIFT = 24;       // a lane's count of parked units lives in its bounce counter above this bit
 
 struct WorkParams {
     int tiles_x;                 // 8x8 tiles across the image
@@ -42,6 +46,8 @@ struct WorkParams {
     int shade_threshold;         // lanes that must be waiting before a shade phase runs while others still search
     int leaf_threshold;          // same for a leaf phase while others still have inner nodes to visit
     int stack_slots;             // per-lane stack slots the launch provides in LDS
+    int parking;                 // 1: a lane whose stack is full moves its oldest entries to TraceArgs::park and carries on;
+                                 // 0: it gives the ordered search up and is resolved by the exhaustive traversal
     int distrust_mask;           // test aid: a winner whose index has none of these bits set is sent to the exhaustive
                                  // traversal as if its box test had failed (negative = never)
     int export_hits;             // the launch reports each path's first-vertex triangle and sphere index (TraceArgs::hit_*):
@@ -66,6 +72,7 @@ struct TraceArgs {
     unsigned long long* stats;
     int* hit_triangle;           // per pixel (row * width + column), written at a path's first vertex; null unless w.export_hits
     int* hit_sphere;
+    int* park;                   // backing store of the lanes' stacks, [entry][thread of the grid]; null unless w.parking
 };
 // The argument struct behind a pointer the compiler must treat as new at this point: what is read through
 // it is fetched here, by scalar loads, instead of being kept in scalar registers across the whole work
@@ -98,11 +105,14 @@ struct WaveShared {
 // NODE32: inner nodes are the 128-byte single-precision nodes with four children (conservative
 // test; the exact test of the winning primitive's own box is made before the path is shaded);
 // otherwise the 128-byte double-precision pairs, whose test is the reference's own.
+// Waves per SIMD the registers are budgeted for: four (128 registers) with the four-wide nodes, whose stacks leave room for
+// four blocks per CU in LDS; the double-precision pairs need their tree's full height in stack slots, so three at most, and
+// the counting and timing builds carry more state than 128 registers hold.
 #ifndef PT_WAVES_PER_SIMD
-#define PT_WAVES_PER_SIMD 3
+#define PT_WAVES_PER_SIMD 4
 #endif
 template <int STATS, bool NODE32, bool MERGED>
-__global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_kernel(TraceArgs args) {
+__global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PER_SIMD : 3) void trace_paths_kernel(TraceArgs args) {
     const DeviceScene& s = args.s;
     const WorkParams& w = args.w;
     unsigned long long* const __restrict__ stats = args.stats;
@@ -197,10 +207,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
         const int top = max(sp - 1, 0);
         const int next = stack_ref[top * BLOCK_THREADS];
         // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
-        // waves per CU).  A lane whose next visit could outgrow its stack gives up the ordered search
+        // waves per CU).  A lane whose next visit could outgrow its stack waits for the next shade phase, which
+        // moves its oldest entries to the backing store (w.parking); without one it gives up the ordered search
         // and is resolved like a tie, by the exhaustive traversal, when it is shaded.
         const bool overflow = sp + 3 > w.stack_slots;
-        tie = tie | overflow;
+        tie = tie | (overflow & (w.parking == 0));
         st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
         sp = top;
         cur = next;
@@ -223,10 +234,36 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             const ArgsInMemory fetched = args_fetched_here();
             const FrameParams& f = *(const FrameParams*)&fetched->f;      // camera and frame: used by this branch only
             const DeviceScene& scene_for_shading = *(const DeviceScene*)&fetched->s;   // materials, normals, background
+            // ---------------- lanes whose stack ran full, or ran empty with entries in the backing store, search on
+            if (NODE32 && fetched->w.parking != 0) {
+                int parked = bounce >> PARKED_SHIFT;
+                if (st == ST_SHADE && (sp > 0 || parked > 0)) {
+                    const long long threads = (long long)gridDim.x * BLOCK_THREADS;
+                    int* const mine = fetched->park + ((long long)blockIdx.x * BLOCK_THREADS + threadIdx.x);
+                    if (sp > 0) {
+                        // full (quad_step left sp within three of the end): the oldest PARK_UNIT entries go out, the rest move down,
+                        // and the lane carries on with the stop it had already taken
+                        for (int k = 0; k < PARK_UNIT; ++k) mine[(parked * PARK_UNIT + k) * threads] = stack_ref[k * BLOCK_THREADS];
+                        for (int k = PARK_UNIT; k < sp; ++k) stack_ref[(k - PARK_UNIT) * BLOCK_THREADS] = stack_ref[k * BLOCK_THREADS];
+                        sp -= PARK_UNIT;
+                        ++parked;
+                        st = (cur < 0) ? ST_LEAF : ST_NODE;
+                    } else {
+                        // empty, but older entries wait outside: the unit parked last comes back
+                        --parked;
+                        for (int k = 0; k < PARK_UNIT; ++k) stack_ref[k * BLOCK_THREADS] = mine[(parked * PARK_UNIT + k) * threads];
+                        sp = PARK_UNIT;
+                        pop_once();
+                    }
+                    bounce = (bounce & ((1 << PARKED_SHIFT) - 1)) | (parked << PARKED_SHIFT);
+                }
+            }
             // ---------------- shade the lanes whose search is over (src/path_tracing.cpp:179-223)
             if (st == ST_SHADE) {
                 Hit ht{best_i, best_t};
                 constexpr bool merged = NODE32 && MERGED;
+                // (with the single-precision nodes the reciprocals are not kept while a ray is searched: see the set-up below)
+                const D3 inv_now = NODE32 ? D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z} : inv;
                 if (NODE32 && best_i >= 0) {
                     // The reference reaches a triangle only through its leaf's box (src/path_tracing.cpp:113-127).
                     // If the winner's box fails the exact test, some other triangle (or none) is the answer: the
@@ -234,7 +271,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     // reciprocals) arrives here with a box it has tested itself.
                     const LeafBox own = fetch_leaf_box(s.tri_boxes + best_i);
                     double tmin, tmax;
-                    box_test(ray.o, inv, own.box, tmin, tmax);
+                    box_test(ray.o, inv_now, own.box, tmin, tmax);
                     tie = tie | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((best_i & w.distrust_mask) == 0));
                 }
                 if (merged) {
@@ -244,7 +281,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                     if (hs.index >= 0) {
                         const LeafBox own = fetch_leaf_box(s.tri_boxes + s.sphere_base + hs.index);
                         double tmin, tmax;
-                        box_test(ray.o, inv, own.box, tmin, tmax);
+                        box_test(ray.o, inv_now, own.box, tmin, tmax);
                         tie_s = tie_s | (tmax < 0.0f) | (tmin > tmax) | ((w.distrust_mask >= 0) & ((hs.index & w.distrust_mask) == 0));
                     }
                     tie = tie | tie_s;
@@ -355,8 +392,16 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
             }
             if (STATS == 2) { const long long t1 = clock64(); ws.t_refill += t1 - t0; t0 = t1; }
             // ---------------- start the search of every new ray (src/path_tracing.cpp:177-178)
-            if (st == ST_NEWRAY) {
+            // With the single-precision nodes a search needs the ray's reciprocals and the single-precision ray only in
+            // the form `r32`, and shading needs neither; both are pure functions of the ray.  They are made again here
+            // for EVERY lane, whatever its state (same values for a lane in mid-search, unused ones for an idle lane),
+            // so that neither occupies registers while the code above runs: that is where the kernel needs most.
+            if (NODE32) {
                 inv = D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+                r32 = make_ray32(ray, inv);
+            }
+            if (st == ST_NEWRAY) {
+                if (!NODE32) inv = D3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
                 constexpr bool merged = NODE32 && MERGED;
                 int kind = NODE32 ? classify_ray_of_bounded_origin(ray, inv) : classify_ray(ray, inv);
                 if (NODE32 && kind == RAY_FINITE && !ray32_allowed(ray, inv)) kind = RAY_EXACT_ONLY;
@@ -394,7 +439,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, PT_WAVES_PER_SIMD) void trace_paths_
                         // Every new ray starts at the same node, so it is visited here and now: the lanes all read
                         // the same 128 bytes (one access per load instead of one per lane), and the search needs
                         // one node phase less.  The hierarchy's own box is not tested: its children's are.
-                        r32 = make_ray32(ray, inv);
                         cut32 = cut32_of(cut);
                         quad_step(0);
                     } else {

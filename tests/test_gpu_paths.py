@@ -16,7 +16,7 @@ from pathtracer_amd import ctypes_abi as abi
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ("PT_KERNEL", "PT_NODES", "PT_BVH", "PT_STATS", "PT_WORKSPACE_GB", "PT_SHADE_THRESHOLD", "PT_LEAF_THRESHOLD",
-            "PT_STACK_SLOTS", "PT_DISTRUST_MASK")
+            "PT_STACK_SLOTS", "PT_DISTRUST_MASK", "PT_PARKING")
 
 
 @pytest.fixture
@@ -116,6 +116,25 @@ def test_a_lane_that_outgrows_its_stack_falls_back_to_the_exhaustive_search(api,
     got = api.DeviceScene.from_host(host).render(small)
     switches()
     assert same_bits(got, api.DeviceScene.from_host(host).render(small))
+
+
+@pytest.mark.parametrize("setting", [{"PT_STACK_SLOTS": 16}, {"PT_STACK_SLOTS": 17}, {"PT_STACK_SLOTS": 20}, {"PT_STACK_SLOTS": 24, "PT_STATS": 1},
+                                     {"PT_STACK_SLOTS": 16, "PT_PARKING": 0}, {"PT_PARKING": 0}])
+def test_a_full_stack_parks_its_oldest_entries_in_device_memory(api, chess, switches, setting):
+    """From 16 slots on, a lane whose LDS stack is full does not give the ordered search up: the next shade phase moves
+    the oldest 12 entries to a backing store in device memory and the lane searches on; when its stack runs empty the
+    unit parked last comes back.  With 16 slots the chess set's searches do that all the time.  PT_PARKING=0 is the launch
+    without a backing store (what pt_render_device_noalloc runs): up to 36 slots, then the exhaustive search."""
+    host, frame, expect = chess
+    switches(**setting)
+    device = api.DeviceScene.from_host(host)
+    got = device.render(frame)
+    deep = host.frame(160, 90, sample_count=3, max_bounces=50)
+    got_deep = device.render(deep)
+    switches(PT_KERNEL="pixels")
+    assert same_bits(got, expect)
+    assert same_bits(got_deep, api.DeviceScene.from_host(host).render(deep))
+    switches()
 
 
 def test_a_winner_whose_box_test_fails_is_resolved_by_the_exhaustive_search(api, chess, switches):
