@@ -1,5 +1,5 @@
 #!/bin/bash
-# Times the benchmark frame for several (shade, leaf) thresholds of the kernel with two searches per lane and reports lanes per phase.
+# Times the benchmark frame for several (shade, leaf) thresholds and reports lanes per phase.
 # usage: profiles/threshold_sweep2.sh <outfile> <scene> <spp> <shade:leaf> ...
 out=$1; scene=$2; spp=$3; shift 3
 mkdir -p "$(dirname "$out")"
