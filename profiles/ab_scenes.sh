@@ -11,6 +11,6 @@ for v in "$@"; do
     echo "== $v $1 $4 ${2}spp depth $3 ${PT_KERNEL:-} window ${PT_STACK_SLOTS:-default}" >> $out
     PT_SIZE=$4 ITERATIONS=3 timeout -k 10 200 python3 profiles/stats_run.py $2 $1 $3 2>/dev/null | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print(json.dumps({'all_ms': d['all_ms'], 'msamples_per_s': round(d['msamples_per_s'])}))" >> $out || exit 1
+d = json.loads(sys.stdin.read()); print(json.dumps({'all_ms': d['all_ms'], 'msamples_per_s': round(d['msamples_per_s']), 'digest': d.get('digest')}))" >> $out || exit 1
   done
 done

@@ -6,6 +6,8 @@
 //   flat      the same through flat loads, all addresses in memory (what the flat form itself costs)
 //   flat+lds  flat loads; a lane whose record is one of the first `top` reads the copy in LDS
 //   branch    two paths: ds_read for the lanes in the top, global loads for the others
+//   awaited   global loads, the first piece awaited before the other six are issued (are loads of a line that is on its
+//             way dearer than loads of a line that is there?)
 // `percent` of the visits go to the first `top` records.  The next index depends on the data read.
 // build: hipcc -O3 --offload-arch=gfx950 -o micro_flat_lds micro_flat_lds.hip
 #include <hip/hip_runtime.h>
@@ -43,6 +45,13 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const char* __restrict__
             asm volatile("" : "+v"(rec));      // the compiler may not prove which address space this is
 #pragma unroll
             for (int k = 0; k < 7; ++k) piece[k] = *reinterpret_cast<const Uint4*>(rec + 16 * k);
+        } else if (MODE == 4) {
+            // the record's line is fetched by one load; the other six are issued once it has arrived
+            const char* rec = table + ((size_t)index << 7);
+            piece[0] = *reinterpret_cast<const Uint4*>(rec);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(piece[0]) :: "memory");
+#pragma unroll
+            for (int k = 1; k < 7; ++k) piece[k] = *reinterpret_cast<const Uint4*>(rec + 16 * k);
         } else {
             if (index < (unsigned)TOP) {
 #pragma unroll
@@ -80,18 +89,19 @@ int main(int argc, char** argv) {
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
-    const char* names[4] = {"global", "flat (all in memory)", "flat + lds", "branch: ds_read | global"};
+    const char* names[5] = {"global", "flat (all in memory)", "flat + lds", "branch: ds_read | global", "global, first piece awaited"};
     std::printf("table %zu MB, %d CUs x 16 waves, %d dependent visits per lane, first %d records also in LDS\n", megabytes, prop.multiProcessorCount,
                 iterations, TOP);
-    const unsigned shares[4] = {0, 20, 40, 60};
+    const unsigned shares[6] = {0, 20, 40, 60, 80, 100};
     for (unsigned share : shares) {
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 5; ++mode) {
             for (int rep = 0; rep < 2; ++rep) {
                 CHECK(hipEventRecord(a));
                 if (mode == 0) hipLaunchKernelGGL(gather_kernel<0>, dim3(blocks), dim3(256), 0, 0, table, records, iterations, share, out);
                 if (mode == 1) hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, 0, table, records, iterations, share, out);
                 if (mode == 2) hipLaunchKernelGGL(gather_kernel<2>, dim3(blocks), dim3(256), 0, 0, table, records, iterations, share, out);
                 if (mode == 3) hipLaunchKernelGGL(gather_kernel<3>, dim3(blocks), dim3(256), 0, 0, table, records, iterations, share, out);
+                if (mode == 4) hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, 0, table, records, iterations, share, out);
                 CHECK(hipGetLastError());
                 CHECK(hipEventRecord(b));
                 CHECK(hipEventSynchronize(b));
