@@ -284,7 +284,7 @@ def main():
             rate = per_path["l1_accesses_per_path"] * launch_paths / launch_s / 1e9
             l1 = {"bound": "l1", "achieved": rate, "peak": l1_peak, "unit": "Gaccess/s", "frac": rate / l1_peak,
                   "basis": f"{per_path['l1_accesses_per_path']:.1f} vector-L1 accesses per path (TCP_TOTAL_CACHE_ACCESSES, {per_path['source']}) x paths "
-                           "/ live kernel time; peak = CUs x 2.4 GHz x one access per cycle (a 16-byte load by lanes on lines of their own: measured)"}
+                           "/ live kernel time; peak = CUs x 2.4 GHz x one access per cycle (measured for 16-byte loads by lanes that stand on lines of their own which come from L2 or beyond, the kernel's case: profiles/r3/micro_l1_pieces.txt, micro_flat_lds.txt)"}
         if per_path is not None:
             tops = per_path["valu_wave_instructions_per_path"] * 64 * launch_paths / launch_s / 1e12
             valu = {"bound": "valu", "achieved": tops, "peak": valu_peak, "unit": "Tlane-op/s", "frac": tops / valu_peak,
