@@ -140,12 +140,13 @@ PT_DEV Float4 min4_3(Float4 a, Float4 b, Float4 c) {
 // host keeps the array below 4 GB), the form the hardware adds by itself.
 PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int node, Float4& lower, Float4& upper, Int4& children) {
     const char* base = reinterpret_cast<const char*>(nodes);
-    const unsigned at = (unsigned)node << 7, at_upper = at + 48u;
+    const unsigned at = (unsigned)node << 7;
     auto field = [&](unsigned offset, int more) { return *reinterpret_cast<const Float4*>(base + (size_t)offset + more); };
-    // every load is issued before the first result is used
-    const Float4 px0 = field(at + r.kx, 0), px1 = field(at_upper - r.kx, 0);
-    const Float4 py0 = field(at + r.ky, 16), py1 = field(at_upper - r.ky, 16);
-    const Float4 pz0 = field(at + r.kz, 32), pz1 = field(at_upper - r.kz, 32);
+    // every load is issued before the first result is used; the far plane lies 48 bytes from the near one, on the other
+    // side of it (k ^ 48 is 48 - k for k = 0 and k = 48, and an exclusive-or and an addition are one instruction)
+    const Float4 px0 = field(at + r.kx, 0), px1 = field(at + (r.kx ^ 48u), 0);
+    const Float4 py0 = field(at + r.ky, 16), py1 = field(at + (r.ky ^ 48u), 16);
+    const Float4 pz0 = field(at + r.kz, 32), pz1 = field(at + (r.kz ^ 48u), 32);
     children = *reinterpret_cast<const Int4*>(base + (size_t)at + 96);
     const Float4 x0 = fma4(px0, r.ix, -r.cnx), x1 = fma4(px1, r.ix, -r.cfx);
     const Float4 y0 = fma4(py0, r.iy, -r.cny), y1 = fma4(py1, r.iy, -r.cfy);

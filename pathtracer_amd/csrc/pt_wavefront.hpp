@@ -199,19 +199,26 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
         const int rank0 = b01 + b02 + b03, rank1 = 1 - b01 + b12 + b13, rank2 = 2 - b02 - b12 + b23, rank3 = 3 - b03 - b13 - b23;
         const int count = (go0 ? 1 : 0) + (go1 ? 1 : 0) + (go2 ? 1 : 0) + (go3 ? 1 : 0);
         const int last = count - 1;
-        stack_ref[(sp + ((last - rank0) & 3)) * BLOCK_THREADS] = c0;
-        stack_ref[(sp + ((last - rank1) & 3)) * BLOCK_THREADS] = c1;
-        stack_ref[(sp + ((last - rank2) & 3)) * BLOCK_THREADS] = c2;
-        stack_ref[(sp + ((last - rank3) & 3)) * BLOCK_THREADS] = c3;
+        // (the LDS address of the four slots above the pending entries is formed once: the compiler otherwise adds `sp` in
+        // again for every child)
+        typedef __attribute__((address_space(3))) int* LdsInts;
+        unsigned frame = (unsigned)(unsigned long long)(LdsInts)stack_ref + (unsigned)sp * (BLOCK_THREADS * 4u);
+        asm volatile("" : "+v"(frame));
+        auto slot_of = [&](int rank) { return (LdsInts)(unsigned long long)(frame + ((unsigned)((last - rank) & 3) << 10)); };
+        static_assert(BLOCK_THREADS * 4 == 1 << 10, "a stack slot of the block is 1 KB");
+        *slot_of(rank0) = c0;
+        *slot_of(rank1) = c1;
+        *slot_of(rank2) = c2;
+        *slot_of(rank3) = c3;
         sp += count;
         const int top = max(sp - 1, 0);
         const int next = stack_ref[top * BLOCK_THREADS];
         // The launch may give a lane fewer slots than the deepest search needs (LDS is what limits the
-        // waves per CU).  A lane whose next visit could outgrow its stack waits for the next shade phase, which
-        // moves its oldest entries to the backing store (w.parking); without one it gives up the ordered search
-        // and is resolved like a tie, by the exhaustive traversal, when it is shaded.
+        // waves per CU).  A lane whose next visit could outgrow its stack waits for the next shade phase with
+        // entries still pending (sp > 0, which no finished search has).  That phase moves its oldest entries to the
+        // backing store (w.parking); without one the lane gives up the ordered search there and is resolved like a
+        // tie, by the exhaustive traversal.
         const bool overflow = sp + 3 > w.stack_slots;
-        tie = tie | (overflow & (w.parking == 0));
         st = ((sp == 0) | overflow) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
         sp = top;
         cur = next;
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             const FrameParams& f = *(const FrameParams*)&fetched->f;      // camera and frame: used by this branch only
             const DeviceScene& scene_for_shading = *(const DeviceScene*)&fetched->s;   // materials, normals, background
             // ---------------- lanes whose stack ran full, or ran empty with entries in the backing store, search on
+            if (NODE32 && fetched->w.parking == 0) tie = tie | ((st == ST_SHADE) & (sp > 0));      // no backing store: see quad_step
             if (NODE32 && fetched->w.parking != 0) {
                 int parked = bounce >> PARKED_SHIFT;
                 if (st == ST_SHADE && (sp > 0 || parked > 0)) {
