@@ -630,7 +630,7 @@ int build_search_nodes(const PtSceneDesc& d, const PairNodes& tri_pairs, bool re
     QuadHierarchy& quads = staging->quads;
     pt::collapse_to_quads(pairs->data(), pairs->size(), &quads);
     clock.done("collapsed to four-wide nodes");
-    if (quads.nodes.size() > (size_t(1) << 25)) return PT_OK;   // the kernel addresses a node by a 32-bit byte offset
+    if (quads.nodes.size() > (size_t(1) << 25) || triangle_count > (1ll << 25)) return PT_OK;   // the kernel addresses a node, and a triangle record, by a 32-bit byte offset
     scene->tri_stack_need = quads.deepest_pending + 4;      // a visit writes four slots above the pending entries
     if (std::getenv("PT_VERBOSE") != nullptr) {
         std::fprintf(stderr, "pathtracer_amd: %zu primitives%s, %lld references more for large triangles, %zu pairs -> %zu four-wide nodes, %d stack slots per lane\n",

@@ -119,6 +119,11 @@ PT_DEV Ray32 make_ray32(const Ray& ray, D3 inv) {
 }
 // Upper bound, as a float, of the pruning distance.
 PT_DEV float cut32_of(double cut) { return (float)((cut + 1.0e-30) * (1.0 + 4.76837158203125e-07)); }
+// The same for the pruning distance that follows a hit at `distance` >= 0 (prune_cut: distance * (1 + 1e-7) + 1e-7), in two
+// single-precision instructions: the conversion loses at most 2^-24 relative, the constant is 1 + 7 * 2^-23 = 1 + 8.3e-7 as
+// a float, the fused operation rounds once more, so the result is at least distance * (1 + 5.9e-7) + 1.09e-7.  Any float at
+// or above the pruning distance serves (a larger one only prunes less).
+PT_DEV float cut32_after_hit(double distance) { return fmaf((float)distance, 1.0f + 8.0e-7f, 1.1e-7f); }
 
 // Conservative bounds of the four child boxes at once, on 4-wide vectors: `lower` <= exact entry
 // distance, `upper` >= exact exit distance.

@@ -468,6 +468,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             // Straight-line code: the whole record is fetched at once and the outcome applied with selects.
             if (st == ST_LEAF) {
                 const int primitive = ~cur;
+                // what the lane visits next is read from its stack before the record is fetched, not after the test
+                const int below = max(sp - 1, 0);
+                const int pending = stack_ref[below * BLOCK_THREADS];
+                // a record is addressed as the array's base plus a 32-bit byte offset (the host keeps the four-wide
+                // hierarchy to scenes of at most 2^25 triangles), the form the hardware adds by itself
+                const TriRecord* const record = reinterpret_cast<const TriRecord*>(reinterpret_cast<const char*>(s.tris) + (size_t)((unsigned)primitive << 7));
                 // With the conservative nodes the leaf's own box has not been tested exactly yet; that test is
                 // made once, on the winning primitive, before the path is shaded.
                 if (NODE32 && MERGED) {
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                     double d = 0.0;
                     bool hit = false;
                     if (is_sphere) hit = hit_sphere(ray, s.spheres + 4 * (primitive - s.sphere_base), d);
-                    else hit = hit_triangle(ray, s.tris + primitive, d);
+                    else hit = hit_triangle(ray, NODE32 ? record : s.tris + primitive, d);
                     // nearest triangle and nearest sphere are kept apart (the reference compares them only at
                     // the end, src/path_tracing.cpp:183); both prune the one search
                     const double own = is_sphere ? hs.distance : best_t;
@@ -492,10 +498,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                     hs.distance = (better & is_sphere) ? d : hs.distance;
                     hs.index = (better & is_sphere) ? primitive - s.sphere_base : hs.index;
                     cut = closer ? cut_d : cut;
-                    cut32 = closer ? cut32_of(cut_d) : cut32;
+                    cut32 = closer ? cut32_after_hit(d) : cut32;
                 } else {
                     double d;
-                    const bool hit = hit_triangle(ray, s.tris + primitive, d);
+                    const bool hit = hit_triangle(ray, NODE32 ? record : s.tris + primitive, d);
                     const bool better = hit & (d < best_t);
                     // (a large triangle is in the hierarchy under several references: meeting the winner again is no tie)
                     const bool equal = hit & (d == best_t) & (primitive != best_i);
@@ -505,9 +511,11 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                     best_t = better ? d : best_t;
                     best_i = better ? primitive : best_i;
                     cut = closer ? cut_d : cut;
-                    if (NODE32) cut32 = closer ? cut32_of(cut_d) : cut32;
+                    if (NODE32) cut32 = closer ? cut32_after_hit(d) : cut32;
                 }
-                pop_once();
+                st = (sp == 0) ? ST_SHADE : ((pending < 0) ? ST_LEAF : ST_NODE);
+                sp = below;
+                cur = pending;
             }
             if (STATS == 2) ws.t_leaf += clock64() - t0;
         } else {
