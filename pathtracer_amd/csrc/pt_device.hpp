@@ -149,6 +149,50 @@ PT_DEV bool hit_triangle(const Ray& ray, const Record* __restrict__ t, double& d
     return !parallel & (dist >= 1.0e-6f) & inside;
 }
 
+// The same test made by the active lanes of a wave together (all of them call it at once), without its two barycentric
+// divisions wherever their outcome is certain.  With A and B the numerators and N = n.n > 0, the reference asks for
+// fl(A/N) >= 0, fl(B/N) >= 0 and fl(fl(A/N) + fl(B/N)) <= 1.  For 1e-150 <= N <= 1e150:
+//   * A < -1e-170 gives a quotient of magnitude >= 1e-320, which does not round to zero: negative, so outside (B alike);
+//   * A >= 0 and B >= 0 (a zero of either sign) with fl(A + B) <= fl(N * (1 - 2^-49)): the three divisions and additions
+//     involved err by 2^-53 relative each, far inside the 2^-49, so the sum of the quotients is <= 1: inside;
+//   * fl(A + B) >= fl(N * (1 + 2^-49)): the sum of the quotients exceeds 1 if both are >= 0, and one of them is negative
+//     otherwise: outside.
+// A lane none of these settles (a point within 2^-49 of the far edge, a numerator between -1e-170 and 0, N out of range, a
+// NaN, for which every comparison is false) makes the whole wave divide; so does nothing else, and the result is the same
+// bits as hit_triangle's either way.
+template <class Record>
+PT_DEV bool hit_triangle_together(const Ray& ray, const Record* __restrict__ t, double& distance) {
+    const D3 a{t->a[0], t->a[1], t->a[2]};
+    const D3 ab{t->ab[0], t->ab[1], t->ab[2]};
+    const D3 ac{t->ac[0], t->ac[1], t->ac[2]};
+    const double nn = t->nn;
+    const D3 n = cross3(ab, ac);
+    const double dn = dot3(ray.d, n);
+    const bool parallel = fabs(dn) < 1.0e-6f;
+    const double dist = dot3(sub3(a, ray.o), n) / dn;
+    const D3 p = add3(ray.o, scale3(dist, ray.d));
+    const D3 ap = sub3(p, a);
+    const double num_a = dot3(cross3(ab, ap), n), num_b = dot3(cross3(ap, ac), n);
+    const bool in_front = dist >= 1.0e-6f;
+    const bool in_range = (nn >= 1.0e-150) & (nn <= 1.0e150);
+    const bool behind_a = num_a < 0.0, behind_b = num_b < 0.0;
+    const bool far_behind = (num_a < -1.0e-170) | (num_b < -1.0e-170);
+    const double sum = num_a + num_b;
+    const bool below = sum <= nn * (1.0 - 0x1p-49), above = sum >= nn * (1.0 + 0x1p-49);
+    const bool surely_inside = in_range & !behind_a & !behind_b & below;
+    const bool surely_outside = in_range & (far_behind | above);
+    // (a lane whose plane distance or direction rules the triangle out needs no inside test at all)
+    const bool settled = surely_inside | surely_outside | parallel | !in_front;
+    bool inside = surely_inside;
+    if (__ballot(!settled) != 0ull) {
+        const double alpha = num_a / nn;
+        const double beta = num_b / nn;
+        inside = (alpha >= 0.0f) & (beta >= 0.0f) & (alpha + beta <= 1.0f);
+    }
+    distance = dist;
+    return !parallel & in_front & inside;
+}
+
 // intersect(ray, sphere), :59-82, followed by the leaf rule of src/path_tracing.cpp:122-125.
 PT_DEV bool hit_sphere_raw(const Ray& ray, const double* __restrict__ s, double& lo, double& hi) {
     const D3 oc = sub3(D3{s[0], s[1], s[2]}, ray.o);

@@ -177,7 +177,11 @@ __global__ void eval_kernel(int op, const void* __restrict__ in, long long n, vo
         t.nn = dot3(nrm, nrm);
         double d;
         const bool ok = hit_triangle(Ray{D3{r[0], r[1], r[2]}, D3{r[3], r[4], r[5]}}, &t, d);
-        dout[2 * i] = ok ? 1.0 : 0.0; dout[2 * i + 1] = d;
+        // the form the wavefront kernel's lanes run together must agree on every input
+        double d_together;
+        const bool ok_together = hit_triangle_together(Ray{D3{r[0], r[1], r[2]}, D3{r[3], r[4], r[5]}}, &t, d_together);
+        const bool same = ok_together == ok && (d_together == d || (d_together != d_together && d != d));
+        dout[2 * i] = same ? (ok ? 1.0 : 0.0) : __builtin_nan(""); dout[2 * i + 1] = d;
         break;
     }
     case PT_EVAL_UNIT_NORMAL: {

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                     double d = 0.0;
                     bool hit = false;
                     if (is_sphere) hit = hit_sphere(ray, s.spheres + 4 * (primitive - s.sphere_base), d);
-                    else hit = hit_triangle(ray, NODE32 ? record : s.tris + primitive, d);
+                    else hit = hit_triangle_together(ray, NODE32 ? record : s.tris + primitive, d);
                     // nearest triangle and nearest sphere are kept apart (the reference compares them only at
                     // the end, src/path_tracing.cpp:183); both prune the one search
                     const double own = is_sphere ? hs.distance : best_t;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                     cut32 = closer ? cut32_after_hit(d) : cut32;
                 } else {
                     double d;
-                    const bool hit = hit_triangle(ray, NODE32 ? record : s.tris + primitive, d);
+                    const bool hit = hit_triangle_together(ray, NODE32 ? record : s.tris + primitive, d);
                     const bool better = hit & (d < best_t);
                     // (a large triangle is in the hierarchy under several references: meeting the winner again is no tie)
                     const bool equal = hit & (d == best_t) & (primitive != best_i);

@@ -86,6 +86,41 @@ def test_device_ray_primitives(api, golden):
     assert same_bits(out, golden["unit_normal_out"])
 
 
+def test_device_triangle_test_on_edges_and_at_odd_scales(api, orc):
+    """The wavefront kernel's lanes test triangles together and skip the two barycentric divisions wherever their outcome is
+    certain (hit_triangle_together; the device compares it with the plain form on every row and answers NaN where they
+    differ).  Rays aimed at points on the edges and vertices of lattice triangles, where alpha + beta is 1 or a numerator
+    is 0 up to the last bit, and the same at scales where n.n leaves the range in which the shortcut is allowed.  Against
+    the checker's intersect(ray, triangle) (src/geometry.cpp:106-133), bit for bit."""
+    rng = np.random.default_rng(2024)
+    count = 60000
+    a = rng.integers(-8, 9, (count, 3)).astype(float) * 2
+    b = a + rng.integers(-6, 7, (count, 3)) * 2
+    c = a + rng.integers(-6, 7, (count, 3)) * 2
+    # barycentric weights with many exact zeros, halves and sums of exactly one
+    w = rng.choice([0.0, 0.0, 0.25, 0.5, 0.5, 0.75, 1.0, 0.3, 0.7, 1e-17, 1.0 - 2.0 ** -52], (count, 2))
+    w[::3, 1] = 1.0 - w[::3, 0]                                     # on the edge opposite a
+    target = a + w[:, :1] * (b - a) + w[:, 1:] * (c - a)
+    origin = rng.integers(-20, 21, (count, 3)).astype(float)
+    origin[::5] = target[::5] + np.eye(3)[rng.integers(0, 3, len(origin[::5]))] * rng.choice([-7.0, 9.0], (len(origin[::5]), 1))   # axis-parallel
+    direction = target - origin
+    length = np.sqrt((direction ** 2).sum(1, keepdims=True))
+    direction = np.where(length > 0, direction / np.where(length > 0, length, 1.0), np.array([[0.0, 0.0, 1.0]]))
+    rays = np.concatenate([origin, direction], 1)
+    tris = np.concatenate([a, b, c], 1)
+    blocks_r, blocks_t = [rays], [tris]
+    for scale in (1e-30, 1e-38, 1e-45, 1e-80, 1e30, 1e38, 1e45, 1e80, 2.0 ** -20, 3.0):
+        part = slice(0, 4000)
+        blocks_r.append(np.concatenate([origin[part] * scale, direction[part]], 1))
+        blocks_t.append(tris[part] * scale)
+    rays, tris = np.concatenate(blocks_r), np.concatenate(blocks_t)
+    with np.errstate(all="ignore"):
+        out = api.device_eval(abi.PT_EVAL_RAY_TRIANGLE, np.concatenate([rays, tris], 1))
+        expect = orc.ray_triangle(rays, tris)
+    assert same_bits(out, expect)
+    assert 0.2 < (expect[:count, 0] == 1.0).mean() < 0.95          # the rows do hit and miss
+
+
 def test_device_scatter(api, golden):
     records = np.concatenate([golden["scatter_rays"], golden["scatter_materials"], golden["scatter_points"], golden["scatter_normals"]], 1)
     assert same_bits(api.device_eval(abi.PT_EVAL_SCATTER, records), golden["scatter_out"])
