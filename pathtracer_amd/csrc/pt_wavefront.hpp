@@ -189,27 +189,33 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             }
             ws.unsafe_skips += __popcll(__ballot(unsafe));
         }
-        // Every child is written to the stack at the place its entry distance gives it, the nearest
-        // on top, skipped ones above the new top (where nothing is read); then the top is taken.
-        // rank = how many children come before this one (ties: lower slot first).  Entry distances are
-        // finite (finite planes and reciprocals), so every entered child ranks before every skipped one.
-        const float far = __builtin_inff();
-        const float k0 = go0 ? low.x : far, k1 = go1 ? low.y : far, k2 = go2 ? low.z : far, k3 = go3 ? low.w : far;
-        const int b01 = k1 < k0, b02 = k2 < k0, b03 = k3 < k0, b12 = k2 < k1, b13 = k3 < k1, b23 = k3 < k2;
-        const int rank0 = b01 + b02 + b03, rank1 = 1 - b01 + b12 + b13, rank2 = 2 - b02 - b12 + b23, rank3 = 3 - b03 - b13 - b23;
+        // The four children are put in descending order of entry distance, skipped ones last, by a five-comparator network
+        // on (distance, reference) pairs, and written to the four slots above the pending entries as they then stand: the
+        // farthest entered child lowest, the nearest on top, skipped ones above the new top (where nothing is read).  The
+        // slots are fixed distances from one address, so the four writes need no address arithmetic of their own.
+        // Entry distances of entered children are finite (finite planes and reciprocals).
+        const float none = -__builtin_inff();
+        float k0 = go0 ? low.x : none, k1 = go1 ? low.y : none, k2 = go2 ? low.z : none, k3 = go3 ? low.w : none;
+        int v0 = c0, v1 = c1, v2 = c2, v3 = c3;
+        auto farther_first = [](float& ka, int& va, float& kb, int& vb) {
+            const bool swap = kb >= ka;      // (of two children entered at the same distance the one in the lower slot is visited first)
+            const float larger = fmaxf(ka, kb), smaller = fminf(ka, kb);
+            const int of_larger = swap ? vb : va, of_smaller = swap ? va : vb;
+            ka = larger; kb = smaller; va = of_larger; vb = of_smaller;
+        };
+        farther_first(k0, v0, k1, v1);
+        farther_first(k2, v2, k3, v3);
+        farther_first(k0, v0, k2, v2);
+        farther_first(k1, v1, k3, v3);
+        farther_first(k1, v1, k2, v2);
         const int count = (go0 ? 1 : 0) + (go1 ? 1 : 0) + (go2 ? 1 : 0) + (go3 ? 1 : 0);
-        const int last = count - 1;
-        // (the LDS address of the four slots above the pending entries is formed once: the compiler otherwise adds `sp` in
-        // again for every child)
         typedef __attribute__((address_space(3))) int* LdsInts;
-        unsigned frame = (unsigned)(unsigned long long)(LdsInts)stack_ref + (unsigned)sp * (BLOCK_THREADS * 4u);
-        asm volatile("" : "+v"(frame));
-        auto slot_of = [&](int rank) { return (LdsInts)(unsigned long long)(frame + ((unsigned)((last - rank) & 3) << 10)); };
         static_assert(BLOCK_THREADS * 4 == 1 << 10, "a stack slot of the block is 1 KB");
-        *slot_of(rank0) = c0;
-        *slot_of(rank1) = c1;
-        *slot_of(rank2) = c2;
-        *slot_of(rank3) = c3;
+        const LdsInts frame = (LdsInts)(unsigned long long)((unsigned)(unsigned long long)(LdsInts)stack_ref + (unsigned)sp * (BLOCK_THREADS * 4u));
+        frame[0] = v0;
+        frame[BLOCK_THREADS] = v1;
+        frame[2 * BLOCK_THREADS] = v2;
+        frame[3 * BLOCK_THREADS] = v3;
         sp += count;
         const int top = max(sp - 1, 0);
         const int next = stack_ref[top * BLOCK_THREADS];
