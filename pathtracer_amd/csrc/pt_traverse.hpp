@@ -59,7 +59,7 @@ struct TreeRef {
 // z) of the four child boxes side by side; an empty slot holds NaN and is never entered.
 struct alignas(128) QuadNode32 {
     float plane[6][4];
-    int32_t child[4];      // >= 0: quad index, < 0: ~primitive
+    int32_t child[4];      // >= 0: quad index, < 0: ~primitive (the planes of x and y carry them a second time: see slab32_quad)
     int32_t pad_[4];
 };
 static_assert(sizeof(QuadNode32) == 128, "QuadNode32 is one 128-byte line");
@@ -143,6 +143,11 @@ PT_DEV Float4 min4_3(Float4 a, Float4 b, Float4 c) {
 }
 // Node `node` of `nodes`: every field is addressed as the array's base plus a 32-bit byte offset (the
 // host keeps the array below 4 GB), the form the hardware adds by itself.
+// CARRIED: the child references are put together from the planes (six 16-byte pieces per visit); otherwise they are
+// fetched as the node's seventh piece.  The first is what a kernel bound by the vector L1's access rate wants (the triangle
+// scenes), the second what one bound by vector issue wants (triangles and spheres in one hierarchy): 16 instructions
+// against one piece.
+template <bool CARRIED>
 PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int node, Float4& lower, Float4& upper, Int4& children) {
     const char* base = reinterpret_cast<const char*>(nodes);
     const unsigned at = (unsigned)node << 7;
@@ -152,7 +157,23 @@ PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int
     const Float4 px0 = field(at + r.kx, 0), px1 = field(at + (r.kx ^ 48u), 0);
     const Float4 py0 = field(at + r.ky, 16), py1 = field(at + (r.ky ^ 48u), 16);
     const Float4 pz0 = field(at + r.kz, 32), pz1 = field(at + (r.kz ^ 48u), 32);
-    children = *reinterpret_cast<const Int4*>(base + (size_t)at + 96);
+    // CARRIED: the child references ride in the planes the step reads anyway.  Byte k of child i's reference is
+    // the lowest mantissa byte of that child's plane in row {0, 3, 1, 4}[k] (lower and upper bound of x, then of y); the host
+    // has moved each of those planes outward to the nearest float that carries its byte (at most 2^-15 relative), so the
+    // planes are used as they are.  Which of the two x (y) rows a lane has in `px0` (`py0`) depends on its ray's direction,
+    // so the byte selectors do too.  v_perm_b32 picks each byte of its result out of the eight bytes of its two sources
+    // (4..7: the first, 0..3: the second; 12: zero).
+    if (CARRIED) {
+        const unsigned from_x = (r.kx == 0u) ? 0x0c0c0400u : 0x0c0c0004u, from_y = (r.ky == 0u) ? 0x04000c0cu : 0x00040c0cu;
+        auto reference = [&](float x_first, float x_second, float y_first, float y_second) {
+            return (int)(__builtin_amdgcn_perm(__float_as_uint(x_second), __float_as_uint(x_first), from_x) |
+                         __builtin_amdgcn_perm(__float_as_uint(y_second), __float_as_uint(y_first), from_y));
+        };
+        children = Int4{reference(px0.x, px1.x, py0.x, py1.x), reference(px0.y, px1.y, py0.y, py1.y),
+                        reference(px0.z, px1.z, py0.z, py1.z), reference(px0.w, px1.w, py0.w, py1.w)};
+    } else {
+        children = *reinterpret_cast<const Int4*>(base + (size_t)at + 96);
+    }
     const Float4 x0 = fma4(px0, r.ix, -r.cnx), x1 = fma4(px1, r.ix, -r.cfx);
     const Float4 y0 = fma4(py0, r.iy, -r.cny), y1 = fma4(py1, r.iy, -r.cfy);
     const Float4 z0 = fma4(pz0, r.iz, -r.cnz), z1 = fma4(pz1, r.iz, -r.cfz);

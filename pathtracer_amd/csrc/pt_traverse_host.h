@@ -19,7 +19,8 @@ struct PairNodeHost {
 static_assert(sizeof(PairNodeHost) == 128, "PairNodeHost mirrors PairNode");
 
 // Same 128 bytes as the device's QuadNode32 (four children: six bounds each, single precision, rounded
-// outward; an empty slot holds NaN bounds and child 0), and the exact boxes beside it (QuadBoxes64).
+// outward; an empty slot holds NaN bounds and child 0), and the exact boxes beside it (QuadBoxes64).  The lowest mantissa
+// bytes of the x and y planes carry the child references a second time (collapse_to_quads puts them there).
 struct QuadNode32Host {
     float plane[6][4];
     int32_t child[4];      // >= 0: quad index, < 0: ~primitive

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
     auto quad_step = [&](const int node) {
         Float4 low, up;
         Int4 children;
-        slab32_quad(r32, s.tri_quads, node, low, up, children);
+        slab32_quad<!MERGED>(r32, s.tri_quads, node, low, up, children);
         const int c0 = children.x, c1 = children.y, c2 = children.z, c3 = children.w;
         // an empty slot holds NaN planes: every comparison below is false for it
         const bool go0 = enter32(low.x, up.x, cut32), go1 = enter32(low.y, up.y, cut32);

@@ -14,7 +14,9 @@
 // balanced subtrees within the remaining levels.
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -372,6 +374,48 @@ struct Collapser {
     }
 };
 
+float float_of_bits(uint32_t bits) { float f; std::memcpy(&f, &bits, sizeof f); return f; }
+
+// The float nearest to `plane` on its outer side (at or below a lower bound, at or above an upper bound) whose lowest
+// mantissa byte is `byte`: at most 255 units in the last place away, 2^-15 relative.  NaN (an empty slot) stays NaN.
+float carrying(float plane, uint32_t byte, bool lower_bound) {
+    if (plane != plane) return float_of_bits(0x7fc00000u | byte);
+    uint32_t bits;
+    std::memcpy(&bits, &plane, sizeof bits);
+    const bool negative = (bits >> 31) != 0;
+    const uint32_t sign = bits & 0x80000000u, magnitude = bits & 0x7fffffffu;
+    uint32_t moved = (magnitude & ~0xffu) | byte;
+    if (negative == lower_bound) {                   // outward is away from zero
+        if (moved < magnitude) moved += 0x100u;
+        return float_of_bits(sign | moved);
+    }
+    if (moved > magnitude) {                         // outward is towards zero, and past it if the magnitude runs out
+        if (moved < 0x100u) return float_of_bits((sign ^ 0x80000000u) | byte);
+        moved -= 0x100u;
+    }
+    return float_of_bits(sign | moved);
+}
+
+// The kernel reads a node's child references out of its planes instead of fetching them: byte k of child i's reference
+// is the lowest mantissa byte of that child's plane in row CARRIER_ROW[k] (lower and upper bound of x, then of y), each
+// plane moved outward to the nearest float that carries its byte.  The references stay in `child` as well, for the host
+// and for the cross-checking build.
+constexpr int CARRIER_ROW[4] = {0, 3, 1, 4};
+void carry_child_references(ptd::QuadNode32Host* nodes, size_t count, int threads) {
+    in_parts(0, static_cast<long long>(count), count >= (size_t(1) << 16) ? threads : 1, [&](long long from, long long to, int) {
+        for (long long n = from; n < to; ++n) {
+            ptd::QuadNode32Host& q = nodes[n];
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t reference = static_cast<uint32_t>(q.child[i]);
+                for (int k = 0; k < 4; ++k) {
+                    const int row = CARRIER_ROW[k];
+                    q.plane[row][i] = carrying(q.plane[row][i], (reference >> (8 * k)) & 0xffu, row < 3);
+                }
+            }
+        }
+    });
+}
+
 }  // namespace
 
 void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::QuadHierarchy* out) {
@@ -382,6 +426,7 @@ void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::Q
     const int threads = host_threads();
     if (pair_count < (size_t(1) << 16)) {
         Collapser{pairs, nullptr, 0, nullptr}.collapse(0, 0, out);
+        carry_child_references(out->nodes.data(), out->nodes.size(), 1);
         return;
     }
     StageClock clock;
@@ -425,6 +470,8 @@ void collapse_to_quads(const ptd::PairNodeHost* pairs, size_t pair_count, ptd::Q
         }
     });
     clock.done("  subtrees put in place");
+    carry_child_references(out->nodes.data(), out->nodes.size(), threads);
+    clock.done("  child references put into the planes");
 }
 
 }  // namespace pt
