@@ -49,7 +49,8 @@ WAVES_PER_SIMD_MAX = 8
 SCENES = {"chess32": abi.PT_SCENE_CHESS32, "chess6": abi.PT_SCENE_CHESS6_ROW, "mixed": abi.PT_SCENE_CHESS32_MIXED,
           "grid": abi.PT_SCENE_CHESS_GRID, "spheres": abi.PT_SCENE_RANDOM_SPHERES, "cornell": abi.PT_SCENE_CORNELL_BOX}
 # bytes the kernel asks the memory hierarchy for, per executed step (what it reads of each record)
-NODE_STEP_BYTES = 112           # six 16-byte plane rows + the four child references of a 128-byte node
+NODE_STEP_BYTES = 96            # six 16-byte plane rows of a 128-byte node (the triangle kernels put the child references together from them)
+NODE_STEP_BYTES_FETCHED_REFERENCES = 112   # the kernel over triangles and spheres together fetches the four child references as well
 TRIANGLE_TEST_BYTES = 80        # a, ab, ac, n.n of a triangle record
 VERTEX_BYTES = 48 + 32 + 40     # the winner's own box, its unit normal + material index, the material
 PATH_STORE_BYTES = 32           # one colour record per path
@@ -155,7 +156,8 @@ def executed_steps(scene, host, width, height, spp, max_bounces, device):
         os.environ.pop("PT_STATS", None)
     paths = max(1, stats["paths"])
     steps = {"node_steps": stats["node_lanes"] / paths, "triangle_tests": stats["leaf_lanes"] / paths, "vertices": stats["shade_lanes"] / paths}
-    steps["bytes_requested"] = (NODE_STEP_BYTES * steps["node_steps"] + TRIANGLE_TEST_BYTES * steps["triangle_tests"]
+    node_bytes = NODE_STEP_BYTES_FETCHED_REFERENCES if len(host.arrays()["spheres"]) > 1 else NODE_STEP_BYTES
+    steps["bytes_requested"] = (node_bytes * steps["node_steps"] + TRIANGLE_TEST_BYTES * steps["triangle_tests"]
                                 + VERTEX_BYTES * steps["vertices"] + PATH_STORE_BYTES)
     lanes = {k: stats[k + "_lanes"] / max(1, stats[k + "_phases"]) for k in ("node", "leaf", "shade")}
     return {"per_path": steps, "active_lanes_of_64_per_phase": lanes, "counted_on": f"{spp} samples per pixel of the same frame",
@@ -165,8 +167,8 @@ def executed_steps(scene, host, width, height, spp, max_bounces, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)      # (the first launches on an idle GPU run 2-3 % slower)
     ap.add_argument("--scene", default="chess32", choices=sorted(SCENES))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
