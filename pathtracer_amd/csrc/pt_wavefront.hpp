@@ -234,9 +234,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
         const unsigned long long m_node = __ballot(st == ST_NODE);
         const unsigned long long m_leaf = __ballot(st == ST_LEAF);
         const bool paths_left = work_left || pool_taken < 64;
-        // no lane is in ST_NEWRAY here (the set-up below resolves it at once): whoever is in none of the three is idle
-        const unsigned long long m_shade = __ballot(st == ST_SHADE);
-        const unsigned long long m_ready = paths_left ? ~(m_node | m_leaf) : m_shade;
+        // no lane is in ST_NEWRAY here (the set-up below resolves it at once): whoever is neither on a node nor on a leaf is
+        // idle or waits to be shaded, and an idle lane is as good as a waiting one while paths are left to hand out
+        unsigned long long m_ready = ~(m_node | m_leaf);
+        if (!paths_left) m_ready = __ballot(st == ST_SHADE);
         const int n_ready = __popcll(m_ready);
         if (STATS) ++ws.loops;
 
