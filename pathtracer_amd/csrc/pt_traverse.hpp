@@ -157,14 +157,16 @@ PT_DEV void slab32_quad(const Ray32 r, const QuadNode32* __restrict__ nodes, int
     const Float4 px0 = field(at + r.kx, 0), px1 = field(at + (r.kx ^ 48u), 0);
     const Float4 py0 = field(at + r.ky, 16), py1 = field(at + (r.ky ^ 48u), 16);
     const Float4 pz0 = field(at + r.kz, 32), pz1 = field(at + (r.kz ^ 48u), 32);
-    // CARRIED: the child references ride in the planes the step reads anyway.  Byte k of child i's reference is
-    // the lowest mantissa byte of that child's plane in row {0, 3, 1, 4}[k] (lower and upper bound of x, then of y); the host
-    // has moved each of those planes outward to the nearest float that carries its byte (at most 2^-15 relative), so the
-    // planes are used as they are.  Which of the two x (y) rows a lane has in `px0` (`py0`) depends on its ray's direction,
-    // so the byte selectors do too.  v_perm_b32 picks each byte of its result out of the eight bytes of its two sources
-    // (4..7: the first, 0..3: the second; 12: zero).
+    // CARRIED: the child references ride in the planes the step reads anyway.  Byte k of child i's reference is the lowest
+    // mantissa byte of that child's plane in row {0, 1, 3, 4}[k] (x lower, y lower, x upper, y upper); the host has moved each
+    // of those planes outward to the nearest float that carries its byte (at most 2^-15 relative), so the planes are used as
+    // they are.  v_perm_b32 picks each byte of its result out of the eight bytes of its two sources (4..7: the first, 0..3:
+    // the second; 12: zero): bytes 0 and 2 come from the two x planes, bytes 1 and 3 from the two y planes.  Which of the
+    // two x (y) rows a lane has in `px0` (`py0`) depends on its ray's direction, and the two selectors that go with the two
+    // cases are each other turned by 16 bits, which is what the offset k (0 or 48) is as a five-bit shift count.
     if (CARRIED) {
-        const unsigned from_x = (r.kx == 0u) ? 0x0c0c0400u : 0x0c0c0004u, from_y = (r.ky == 0u) ? 0x04000c0cu : 0x00040c0cu;
+        const unsigned from_x = __builtin_amdgcn_alignbit(0x0c040c00u, 0x0c040c00u, r.kx);
+        const unsigned from_y = __builtin_amdgcn_alignbit(0x040c000cu, 0x040c000cu, r.ky);
         auto reference = [&](float x_first, float x_second, float y_first, float y_second) {
             return (int)(__builtin_amdgcn_perm(__float_as_uint(x_second), __float_as_uint(x_first), from_x) |
                          __builtin_amdgcn_perm(__float_as_uint(y_second), __float_as_uint(y_first), from_y));

@@ -397,10 +397,10 @@ float carrying(float plane, uint32_t byte, bool lower_bound) {
 }
 
 // The kernel reads a node's child references out of its planes instead of fetching them: byte k of child i's reference
-// is the lowest mantissa byte of that child's plane in row CARRIER_ROW[k] (lower and upper bound of x, then of y), each
-// plane moved outward to the nearest float that carries its byte.  The references stay in `child` as well, for the host
-// and for the cross-checking build.
-constexpr int CARRIER_ROW[4] = {0, 3, 1, 4};
+// is the lowest mantissa byte of that child's plane in row CARRIER_ROW[k] (lower bound of x, of y, upper bound of x, of y),
+// each plane moved outward to the nearest float that carries its byte.  The references stay in `child` as well, for the
+// host, the cross-checking build and the kernel that fetches them.
+constexpr int CARRIER_ROW[4] = {0, 1, 3, 4};
 void carry_child_references(ptd::QuadNode32Host* nodes, size_t count, int threads) {
     in_parts(0, static_cast<long long>(count), count >= (size_t(1) << 16) ? threads : 1, [&](long long from, long long to, int) {
         for (long long n = from; n < to; ++n) {
