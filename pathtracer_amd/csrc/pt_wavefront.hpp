@@ -241,7 +241,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
         const int n_ready = __popcll(m_ready);
         if (STATS) ++ws.loops;
 
-        if ((m_node | m_leaf) == 0ull || n_ready >= w.shade_threshold) {
+        const bool shade_now = (m_node | m_leaf) == 0ull || n_ready >= w.shade_threshold;
+        const bool leaf_now = !shade_now && (m_node == 0ull || __popcll(m_leaf) >= w.leaf_threshold);
+        if (shade_now) {
             if (n_ready == 0) break;      // nothing in flight, nothing to shade, no work left
             if (STATS) { ++ws.shade_phases; ws.shade_lanes += n_ready; }
             if (STATS == 2) t0 = clock64();
@@ -468,7 +470,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                 }
             }
             if (STATS == 2) ws.t_setup += clock64() - t0;
-        } else if (m_node == 0ull || __popcll(m_leaf) >= w.leaf_threshold) {
+        }
+        if (leaf_now) {
             // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
             if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(m_leaf); }
             if (STATS == 2) t0 = clock64();
@@ -525,7 +528,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                 cur = pending;
             }
             if (STATS == 2) ws.t_leaf += clock64() - t0;
-        } else {
+        }
+        if (!shade_now && !leaf_now) {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS == 2) t0 = clock64();
             // Straight-line code: all four children are written to the stack, skipped ones above its new top
