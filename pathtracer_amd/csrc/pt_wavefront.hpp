@@ -426,9 +426,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
                 if (s.sph_tree.count == 1) {
                     // one sphere: its node is the root and a leaf; the reference tests the box, then the sphere
                     // (src/path_tracing.cpp:113-127); min/max order matters only if a slab product is NaN
-                    double tmin, tmax, d;
-                    box_test(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
-                    if (!(tmax < 0.0f || tmin > tmax) && hit_sphere(ray, s.spheres, d)) hs = Hit{0, d};
+                    // (both tests are pure: the sphere's comes first here because most rays fail it, and the box's is then
+                    // made by the lanes that passed, if any)
+                    double d;
+                    if (hit_sphere(ray, s.spheres, d)) {
+                        double tmin, tmax;
+                        box_test(ray.o, inv, s.sph_tree.root_box, tmin, tmax);
+                        if (!(tmax < 0.0f || tmin > tmax)) hs = Hit{0, d};
+                    }
                 } else if (!merged) {
                     // spheres outside the search hierarchy: the lane walks the sphere tree on its own
                     hs = trace_tree(ray, s.sph_tree, sph_leaf, REAL_MAX, stack_ref, frames);
