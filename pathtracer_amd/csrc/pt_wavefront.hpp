@@ -534,7 +534,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             }
             if (STATS == 2) ws.t_leaf += clock64() - t0;
         }
-        if (!shade_now && !leaf_now) {
+        // (a node step follows a leaf phase in the same iteration: the lanes that the leaf phase put on a node join it at once)
+        if (!shade_now) {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS == 2) t0 = clock64();
             // Straight-line code: all four children are written to the stack, skipped ones above its new top
