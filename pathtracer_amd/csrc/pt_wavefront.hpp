@@ -534,13 +534,13 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             }
             if (STATS == 2) ws.t_leaf += clock64() - t0;
         }
-        // (a node step follows a leaf phase in the same iteration: the lanes that the leaf phase put on a node join it at once)
-        if (!shade_now) {
+        // (a node step follows a leaf phase or a shade phase in the same iteration: the lanes that the phase put on a node join it at once)
+        {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS == 2) t0 = clock64();
             // Straight-line code: all four children are written to the stack, skipped ones above its new top
             // (the launch sizes the stack for it), and every decision is a select.
-            if (STATS) { ++ws.node_phases; ws.node_lanes += __popcll(__ballot(st == ST_NODE)); }
+            if (STATS) { const int on_a_node = __popcll(__ballot(st == ST_NODE)); ws.node_phases += on_a_node > 0 ? 1 : 0; ws.node_lanes += on_a_node; }
             if (st == ST_NODE) {
                 if (NODE32) {
                     quad_step(cur);
