@@ -108,6 +108,9 @@ struct WaveShared {
 // Waves per SIMD the registers are budgeted for: four (128 registers) with the four-wide nodes, whose stacks leave room for
 // four blocks per CU in LDS; the double-precision pairs need their tree's full height in stack slots, so three at most, and
 // the counting and timing builds carry more state than 128 registers hold.
+#ifndef PT_REPEAT_LANES
+#define PT_REPEAT_LANES 16      // lanes that must still stand on a node for an iteration's second node step
+#endif
 #ifndef PT_WAVES_PER_SIMD
 #define PT_WAVES_PER_SIMD 4
 #endif
@@ -536,6 +539,40 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
         }
         // (a node step follows a leaf phase or a shade phase in the same iteration: the lanes that the phase put on a node join it at once)
         {
+            // ---------------- one inner-node step: both children's boxes, nearer child first
+            if (STATS == 2) t0 = clock64();
+            // Straight-line code: all four children are written to the stack, skipped ones above its new top
+            // (the launch sizes the stack for it), and every decision is a select.
+            if (STATS) { const int on_a_node = __popcll(__ballot(st == ST_NODE)); ws.node_phases += on_a_node > 0 ? 1 : 0; ws.node_lanes += on_a_node; }
+            if (st == ST_NODE) {
+                if (NODE32) {
+                    quad_step(cur);
+                } else {
+                    const PairNode* p = s.tri_tree.pairs + cur;
+                    const int lref = p->left, rref = p->right;
+                    double lmin, lmax, rmin, rmax;
+                    slab_finite(ray.o, inv, p->lbox[0], p->lbox[1], p->lbox[2], p->lbox[3], p->lbox[4], p->lbox[5], lmin, lmax);
+                    slab_finite(ray.o, inv, p->rbox[0], p->rbox[1], p->rbox[2], p->rbox[3], p->rbox[4], p->rbox[5], rmin, rmax);
+                    const bool go_l = !(lmax < 0.0f || lmin > lmax) && !(lmin > cut);
+                    const bool go_r = !(rmax < 0.0f || rmin > rmax) && !(rmin > cut);
+                    const bool left_first = !(rmin < lmin);
+                    const bool both = go_l && go_r;
+                    const int near = (both ? left_first : go_l) ? lref : rref;
+                    stack_ref[sp * BLOCK_THREADS] = left_first ? rref : lref;
+                    sp += both ? 1 : 0;
+                    const bool stuck = !(go_l || go_r);
+                    const int top = max(sp - 1, 0);
+                    const int pending = stack_ref[top * BLOCK_THREADS];
+                    const int next = stuck ? pending : near;
+                    st = (stuck && sp == 0) ? ST_SHADE : ((next < 0) ? ST_LEAF : ST_NODE);
+                    sp = stuck ? top : sp;
+                    cur = next;
+                }
+            }
+            if (STATS == 2) ws.t_node += clock64() - t0;
+        }
+        // (and a second one, when enough lanes are still on a node)
+        if (__popcll(__ballot(st == ST_NODE)) >= PT_REPEAT_LANES) {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS == 2) t0 = clock64();
             // Straight-line code: all four children are written to the stack, skipped ones above its new top
