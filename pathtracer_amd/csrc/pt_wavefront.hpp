@@ -608,7 +608,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
         // (and a leaf phase at the end of the iteration when the node steps have put enough lanes on leaves)
         if (__popcll(__ballot(st == ST_LEAF)) >= w.leaf_threshold) {
             // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
-            if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(m_leaf); }
+            if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(__ballot(st == ST_LEAF)); }
             if (STATS == 2) t0 = clock64();
             // Straight-line code: the whole record is fetched at once and the outcome applied with selects.
             if (st == ST_LEAF) {
