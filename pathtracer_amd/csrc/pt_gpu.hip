@@ -718,8 +718,8 @@ struct Tunables {
     int blocks_per_cu = 0;              // PT_BLOCKS_PER_CU: persistent blocks per CU (0 = occupancy query)
     bool force_f64_nodes = false;       // PT_NODES=f64: double-precision inner nodes in the wavefront kernel
     bool reference_topology = false;    // PT_BVH=reference: search the reference's own tree shape instead of the SAH rebuild
-    int shade_threshold = 40;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams (swept: profiles/r3/thresholds_presplit.log)
-    int leaf_threshold = 16;
+    int shade_threshold = 40;           // PT_SHADE_THRESHOLD / PT_LEAF_THRESHOLD: see WorkParams (swept: profiles/r3/thresholds_final_flow.log)
+    int leaf_threshold = 12;
     int stack_slots = 0;                // PT_STACK_SLOTS: per-lane stack slots of the 4-wide search (0 = what the scene needs, capped)
     int distrust_mask = -1;             // PT_DISTRUST_MASK: see WorkParams (3 sends every fourth winner to the fallback)
     bool parking = true;                // PT_PARKING=0: no backing store for the lanes' stacks (a full stack ends the ordered search)

@@ -245,7 +245,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
         if (STATS) ++ws.loops;
 
         const bool shade_now = (m_node | m_leaf) == 0ull || n_ready >= w.shade_threshold;
-        const bool leaf_now = !shade_now && (m_node == 0ull || __popcll(m_leaf) >= w.leaf_threshold);
         if (shade_now) {
             if (n_ready == 0) break;      // nothing in flight, nothing to shade, no work left
             if (STATS) { ++ws.shade_phases; ws.shade_lanes += n_ready; }
@@ -479,65 +478,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             }
             if (STATS == 2) ws.t_setup += clock64() - t0;
         }
-        if (leaf_now) {
-            // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
-            if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(m_leaf); }
-            if (STATS == 2) t0 = clock64();
-            // Straight-line code: the whole record is fetched at once and the outcome applied with selects.
-            if (st == ST_LEAF) {
-                const int primitive = ~cur;
-                // what the lane visits next is read from its stack before the record is fetched, not after the test
-                const int below = max(sp - 1, 0);
-                const int pending = stack_ref[below * BLOCK_THREADS];
-                // a record is addressed as the array's base plus a 32-bit byte offset (the host keeps the four-wide
-                // hierarchy to scenes of at most 2^25 triangles), the form the hardware adds by itself
-                const TriRecord* const record = reinterpret_cast<const TriRecord*>(reinterpret_cast<const char*>(s.tris) + (size_t)((unsigned)primitive << 7));
-                // With the conservative nodes the leaf's own box has not been tested exactly yet; that test is
-                // made once, on the winning primitive, before the path is shaded.
-                if (NODE32 && MERGED) {
-                    const bool is_sphere = primitive >= s.sphere_base;
-                    double d = 0.0;
-                    bool hit = false;
-                    if (is_sphere) hit = hit_sphere(ray, s.spheres + 4 * (primitive - s.sphere_base), d);
-                    else hit = hit_triangle_together(ray, NODE32 ? record : s.tris + primitive, d);
-                    // nearest triangle and nearest sphere are kept apart (the reference compares them only at
-                    // the end, src/path_tracing.cpp:183); both prune the one search
-                    const double own = is_sphere ? hs.distance : best_t;
-                    const double other = is_sphere ? best_t : hs.distance;
-                    const bool better = hit & (d < own);
-                    // (a large triangle is in the hierarchy under several references: meeting the winner again is no tie)
-                    const bool equal = hit & (d == own) & (is_sphere | (primitive != best_i));
-                    const bool closer = better & (d < other) & (w.export_hits == 0);    // reporting both indices: nothing is pruned by a hit
-                    const double cut_d = prune_cut(d);
-                    tie = is_sphere ? tie : ((tie & !better) | equal);
-                    tie_s = is_sphere ? ((tie_s & !better) | equal) : tie_s;
-                    best_t = (better & !is_sphere) ? d : best_t;
-                    best_i = (better & !is_sphere) ? primitive : best_i;
-                    hs.distance = (better & is_sphere) ? d : hs.distance;
-                    hs.index = (better & is_sphere) ? primitive - s.sphere_base : hs.index;
-                    cut = closer ? cut_d : cut;
-                    cut32 = closer ? cut32_after_hit(d) : cut32;
-                } else {
-                    double d;
-                    const bool hit = hit_triangle_together(ray, NODE32 ? record : s.tris + primitive, d);
-                    const bool better = hit & (d < best_t);
-                    // (a large triangle is in the hierarchy under several references: meeting the winner again is no tie)
-                    const bool equal = hit & (d == best_t) & (primitive != best_i);
-                    const bool closer = better & (d < hs.distance);
-                    const double cut_d = prune_cut(d);
-                    tie = (tie & !better) | equal;
-                    best_t = better ? d : best_t;
-                    best_i = better ? primitive : best_i;
-                    cut = closer ? cut_d : cut;
-                    if (NODE32) cut32 = closer ? cut32_after_hit(d) : cut32;
-                }
-                st = (sp == 0) ? ST_SHADE : ((pending < 0) ? ST_LEAF : ST_NODE);
-                sp = below;
-                cur = pending;
-            }
-            if (STATS == 2) ws.t_leaf += clock64() - t0;
-        }
-        // (a node step follows a leaf phase or a shade phase in the same iteration: the lanes that the phase put on a node join it at once)
+        // (a node step follows a shade phase in the same iteration: the rays it set up have visited the first node and mostly stand on one)
         {
             // ---------------- one inner-node step: both children's boxes, nearer child first
             if (STATS == 2) t0 = clock64();
@@ -605,8 +546,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (NODE32 && STATS == 0) ? PT_WAVES_PE
             }
             if (STATS == 2) ws.t_node += clock64() - t0;
         }
-        // (and a leaf phase at the end of the iteration when the node steps have put enough lanes on leaves)
-        if (__popcll(__ballot(st == ST_LEAF)) >= w.leaf_threshold) {
+        // ---------------- leaf visits, when enough lanes stand on a leaf by now or none is left on a node
+        const unsigned long long on_a_leaf = __ballot(st == ST_LEAF);
+        if (__popcll(on_a_leaf) >= w.leaf_threshold || (on_a_leaf != 0ull && __ballot(st == ST_NODE) == 0ull)) {
             // ---------------- leaf visits: the reference's box test on the leaf's own box, then the triangle
             if (STATS) { ++ws.leaf_phases; ws.leaf_lanes += __popcll(__ballot(st == ST_LEAF)); }
             if (STATS == 2) t0 = clock64();
