@@ -222,20 +222,28 @@ PT_DEV bool hit_sphere(const Ray& ray, const double* __restrict__ s, double& dis
 struct Mat { double v0, v1, v2, v3; int type; };
 
 // scatter (src/path_tracing.cpp:35-97) with reflect (:7-12), refract (:14-24), reflectance (:27-33).
-PT_DEV bool scatter(const Ray& in, const Mat& m, D3 p, D3 n, Ray& out) {
+// `with_metals`, the same for every lane: the scene has a metal among its materials.  Lambertian and metal are then one
+// body, `unit(base + k * random_unit_vector(in.d))` from the nudged point, so that lanes of the two kinds run its square
+// roots and divisions (most of a shade phase) together instead of one kind after the other.  Same operations on the
+// same operands either way.
+PT_DEV bool scatter(const Ray& in, const Mat& m, D3 p, D3 n, Ray& out, bool with_metals) {
     const double nudge = 0.001f;
-    if (m.type == PT_LAMBERTIAN) {
+    if (with_metals) {
+        if (m.type == PT_LAMBERTIAN || m.type == PT_METAL) {
+            const bool metal = m.type == PT_METAL;
+            const D3 rnd = random_unit_vector(in.d);
+            const D3 refl = sub3(in.d, scale3(2.0f * dot3(in.d, n), n));
+            const D3 base = metal ? refl : n;
+            const double k = metal ? m.v3 : 0.99f;
+            out.o = add3(p, scale3(nudge, n));
+            out.d = unit3(add3(base, scale3(k, rnd)));
+            return !metal || dot3(out.d, n) > 0.0f;
+        }
+    } else if (m.type == PT_LAMBERTIAN) {
         const D3 rnd = random_unit_vector(in.d);
         out.o = add3(p, scale3(nudge, n));
         out.d = unit3(add3(n, scale3(0.99f, rnd)));
         return true;
-    }
-    if (m.type == PT_METAL) {
-        const D3 rnd = random_unit_vector(in.d);
-        const D3 refl = sub3(in.d, scale3(2.0f * dot3(in.d, n), n));
-        out.o = add3(p, scale3(nudge, n));
-        out.d = unit3(add3(refl, scale3(m.v3, rnd)));
-        return dot3(out.d, n) > 0.0f;
     }
     if (m.type == PT_DIELECTRIC) {
         const bool front = dot3(in.d, n) < 0.0f;

@@ -206,6 +206,7 @@ struct DeviceScene {
     int32_t sphere_base;             // INT_MAX when the spheres are not part of the hierarchy
     int32_t search_root;             // child reference of the hierarchy's root (0, or ~primitive if there is one primitive)
     int32_t search_count;            // primitives in the hierarchy
+    int32_t with_metals;             // some material is a metal (scatter then treats Lambertian and metal lanes together)
     double search_box[6];            // exact box of everything in it
     TreeRef sph_tree;
     const double* spheres;        // 4 doubles each
@@ -444,7 +445,7 @@ PT_DEV bool shade_vertex(const DeviceScene& s, Ray& ray, const Hit& hs, const Hi
         gain = D3{0.0f, 0.0f, 0.0f};                                       // get_emission, src/material.cpp:64-81
         if (m.type == PT_DIFFUSE_LIGHT) gain = scale3(m.v3, D3{m.v0, m.v1, m.v2});
         Ray next;
-        const bool valid = scatter(ray, m, p, n, next);
+        const bool valid = scatter(ray, m, p, n, next, s.with_metals != 0);
         if (valid) {
             ray = next;
             D3 albedo;                                                     // get_colour, src/material.cpp:39-62
