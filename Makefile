@@ -11,7 +11,10 @@ CSRC     := pathtracer_amd/csrc
 LIB      := pathtracer_amd/libpathtracer_amd.so
 
 HOSTFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -pthread -Wall -Wextra -Wno-unused-parameter
-HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-parameter $(EXTRA_HIPFLAGS)
+# The GPU code is scheduled by the compiler's "max-memory-clause" strategy: the loads of a node or triangle record
+# leave together, ahead of the arithmetic that does not need them (measured: 2.4 % on the chess set, 1-3 % elsewhere;
+# the order of instructions only, no operation is changed).
+HIPFLAGS  := -std=c++17 -O3 -ffp-contract=off -fPIC --offload-arch=$(ARCH) -mllvm -amdgpu-sched-strategy=max-memory-clause -Wall -Wno-unused-parameter $(EXTRA_HIPFLAGS)
 
 HOST_SRCS := $(CSRC)/host_core.cpp $(CSRC)/bvh_build.cpp $(CSRC)/scenes.cpp $(CSRC)/sah_build.cpp $(CSRC)/presplit.cpp
 HOST_OBJS := $(HOST_SRCS:.cpp=.o)
