@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the tables and DESIGN.md quote, measured on the tree as it stands: the GPU test suite, the five workloads under
+# Everything the counter tables and the documentation quote, measured on the tree as it stands: the GPU test suite, the five workloads under
 # rocprofv3 (kernel trace, then one counter pass per group), phase counts, shard times.
 set -o pipefail
 mkdir -p gpurun_out/r3

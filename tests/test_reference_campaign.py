@@ -26,7 +26,7 @@ def run_case(kind, seed):
 def judge(kind, seed, unbounded):
     code, last, err = run_case(kind, seed)
     if code == -signal.SIGABRT and last.get("stage") in ("built", "reference hits"):
-        # the reference's own assert stopped it; the restatement and the library define a result there (DESIGN, section 3.1)
+        # the reference's own assert stopped it; the restatement and the library define a result there (the vertex is the sphere's, the one index that exists)
         assert unbounded, f"{kind} {seed}: the reference asserts on a bounded input:\n{err}"
         return "reference asserts"
     assert code == 0 and last.get("stage") == "done", f"{kind} {seed}: exit {code}, last {last}:\n{err}"
