@@ -153,6 +153,30 @@ def test_a_callers_tree_whose_boxes_do_not_nest_is_searched_as_it_is(api, orc):
         api.construct_triangle_bvh(bad)
 
 
+def test_a_metal_among_the_materials_changes_nothing_else(api, orc):
+    """A scene with a metal in its material table scatters Lambertian and metal lanes in one body, a scene without one
+    keeps the Lambertian body alone: the same triangles and spheres rendered with a table that holds no metal, and with
+    the same table plus a metal nothing uses, give the same bytes (and the checker's)."""
+    from oracle.bindings import make_desc
+    rng = np.random.default_rng(77)
+    centre = rng.uniform(-5, 5, (200, 1, 3))
+    triangles = (centre + rng.normal(0, 1.2, (200, 3, 3))).reshape(-1, 9)
+    spheres = np.concatenate([rng.uniform(-5, 5, (6, 3)), rng.uniform(0.4, 1.5, (6, 1))], 1)
+    without = _materials()[[0, 2, 3]]                      # Lambertian, glass, light
+    arrays = _scene(api, triangles, spheres, tri_materials=rng.integers(0, 3, 200), sph_materials=rng.integers(0, 3, 6))
+    arrays["materials"] = without
+    unused = _materials()[[0, 2, 3, 1]]                    # the same three, then a metal no primitive refers to
+    renders = []
+    for table in (without, unused):
+        arrays["materials"] = table
+        desc, keep = make_desc(arrays)
+        device = api.DeviceScene(desc, keepalive=keep)
+        cam = api.camera_look_at((0.0, 2.0, 14.0), (0.0, 0.0, 0.0), 0.7, 0.05)
+        frame = api.camera_frame(cam, 4 / 3, 64, 48, sample_count=4, max_bounces=20)
+        renders.append(device.render(frame))
+    assert same_bits(renders[0], renders[1])
+    assert same_bits(renders[0], orc.scene_create(arrays).render(frame, threads=4))
+
 # PT_RANDOM_SCENES=<n> widens the campaign (a one-off run of 500 is logged under profiles/r2/); seeds from 16 on also draw
 # soups of 3,000 and 30,000 triangles.
 @pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("PT_RANDOM_SCENES", "16")))) | {27, 63}))     # 63: hollow spheres under boxes that do not hold them; 27: infinite coordinates
